@@ -1,0 +1,82 @@
+"""ctypes binding of libaccv_hip.so (the gfx950 C-ABI declared in include/accv_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an exception is
+raised — the product path never routes through a CPU or eager-PyTorch substitute.
+Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C accv-lab_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaccv_hip.so")
+
+OK = 0
+HM_CLEAR = 1
+HM_COUNTS_I64 = 2
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_u = ctypes.c_uint
+_sz = ctypes.c_size_t
+_i64 = ctypes.c_int64
+
+# name -> (restype, argtypes); must list every symbol include/accv_hip.h declares (tests check this)
+SIGNATURES = {
+    "accv_last_error": (ctypes.c_char_p, []),
+    "accv_version": (_i, []),
+    "accv_draw_heatmap_flat_workspace_bytes": (_sz, [_i, _i]),
+    "accv_draw_heatmap_flat_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _u, _vp, _sz, _vp]),
+    "accv_draw_heatmap_batched_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _u, _vp]),
+    "accv_fill_f32": (_i, [_vp, _sz, _f, _vp]),
+}
+# not in the public header (bench / profiling knobs)
+_PRIVATE = {
+    "accv_tune_set": (_i, [ctypes.c_char_p, _i]),
+}
+
+_lib = None
+
+
+class AccvNativeError(RuntimeError):
+    """Raised when a libaccv_hip.so entry point reports a failure (mirrors the reference's TORCH_CHECK ->
+    RuntimeError behaviour)."""
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `make -C accv-lab_amd/csrc` or __graft_entry__.build()). There is no CPU fallback."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for table in (SIGNATURES, _PRIVATE):
+            for name, (res, args) in table.items():
+                fn = getattr(handle, name)
+                fn.restype = res
+                fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != OK:
+        msg = lib().accv_last_error()
+        raise AccvNativeError(f"{what}: {msg.decode() if msg else 'error'} (status {status})")
+
+
+def tune_set(key: str, value: int) -> None:
+    check(lib().accv_tune_set(key.encode(), int(value)), "accv_tune_set")
+
+
+def stream_ptr(device) -> int:
+    """hipStream_t of torch's CURRENT stream on `device` (the reference launches on
+    at::cuda::getCurrentCUDAStream(), draw_heatmap_cuda.cu:65)."""
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,12 @@
+"""accvlab.draw_heatmap — MI355X-native drop-in for the reference package of the same name.
+
+Public API (same names, argument meaning and error behaviour as
+packages/draw_heatmap/accvlab/draw_heatmap/__init__.py:22-24 of the reference):
+``draw_heatmap`` (flat / "concatenated" input) and ``draw_heatmap_batched`` (RaggedBatch input, optional
+class-wise planes).  Both accept one extra keyword, ``clear=False``: with ``clear=True`` the map is
+overwritten with max(0, splats) in a single write-only pass (fused zero-fill + draw).
+"""
+from .ops import draw_heatmap, draw_heatmap_batched
+
+__version__ = "0.1.0"
+__all__ = ["__version__", "draw_heatmap", "draw_heatmap_batched"]

@@ -1,0 +1,174 @@
+"""Host side of the Gaussian heat-map rasteriser: argument validation + one C-ABI call per op.
+
+Mirrors the checks of the reference launchers (packages/draw_heatmap/accvlab/draw_heatmap/csrc/
+draw_heatmap_cuda.cu:62-89, 91-124, 126-165) and of the python wrapper
+(funtions/draw_heatmap_batched.py:27-84): tensor-property violations raise ``RuntimeError``,
+RaggedBatch shape mismatches raise ``AssertionError``.  All work is enqueued on torch's current stream of
+the heat-map's device; nothing synchronises.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _amd_native as _nat
+
+
+def _require(cond: bool, msg: str) -> None:
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_input(t: torch.Tensor, name: str) -> None:
+    _require(isinstance(t, torch.Tensor), f"{name} must be a torch.Tensor")
+    _require(t.is_cuda, f"{name} must be a CUDA tensor")
+    _require(t.is_contiguous(), f"{name} must be contiguous")
+
+
+def _check_dtype(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
+    _require(t.dtype == dtype, f"{name}: expected scalar type {dtype} but found {t.dtype}")
+
+
+def _same_device(ref: torch.Tensor, *others) -> None:
+    for name, t in others:
+        _require(t.device == ref.device, f"{name} must be on the same device as the heatmap ({ref.device})")
+
+
+def draw_heatmap(
+    heatmaps: torch.Tensor,
+    centers: torch.Tensor,
+    radii: torch.Tensor,
+    heatmap_idxes: torch.Tensor,
+    diameter_to_sigma_factor: float = 6.0,
+    k_scale: float = 1.0,
+    *,
+    clear: bool = False,
+) -> None:
+    """Draw N Gaussians into ``heatmaps[P,H,W]`` (fp32, in place, element-wise max).
+
+    Args:
+        heatmaps: float32 ``[num_heatmaps, height, width]``, modified in place.
+        centers: int32 ``[N, 2]`` as (x, y).
+        radii: int32 ``[N]``.
+        heatmap_idxes: int32 ``[N]`` — plane each object is drawn into.
+        diameter_to_sigma_factor: sigma = (2r+1) / factor.
+        k_scale: peak value.
+        clear: (extension) overwrite the map with max(0, splats) instead of max-ing into its content.
+
+    Reference: draw_heatmap.cpp:132-134 -> draw_heatmap_launcher (draw_heatmap_cuda.cu:62-89).
+    """
+    _check_input(heatmaps, "heatmap")
+    _check_input(centers, "centers")
+    _check_input(radii, "radii")
+    _check_input(heatmap_idxes, "heatmap_idxes")
+    _require(centers.size(0) == radii.size(0), "centers and radii must have the same size at dim0")
+    _require(centers.size(0) == heatmap_idxes.size(0), "centers and heatmap_idxes must have the same size at dim0")
+    _require(heatmaps.dim() == 3, "heatmap must be of shape [num_heatmaps, height, width]")
+    _require(centers.dim() == 2 and centers.size(1) == 2, "centers must be of shape [num_targets, 2]")
+    _require(radii.dim() == 1 and heatmap_idxes.dim() == 1, "radii and heatmap_idxes must be of shape [num_targets]")
+    _check_dtype(heatmaps, torch.float32, "heatmap")
+    _check_dtype(centers, torch.int32, "centers")
+    _check_dtype(radii, torch.int32, "radii")
+    _check_dtype(heatmap_idxes, torch.int32, "heatmap_idxes")
+    _same_device(heatmaps, ("centers", centers), ("radii", radii), ("heatmap_idxes", heatmap_idxes))
+
+    lib = _nat.lib()
+    planes, height, width = heatmaps.shape
+    n = centers.size(0)
+    with torch.cuda.device(heatmaps.device):
+        ws_bytes = lib.accv_draw_heatmap_flat_workspace_bytes(planes, n)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=heatmaps.device)
+        status = lib.accv_draw_heatmap_flat_f32(
+            heatmaps.data_ptr(), planes, height, width, centers.data_ptr(), radii.data_ptr(),
+            heatmap_idxes.data_ptr(), n, float(diameter_to_sigma_factor), float(k_scale),
+            _nat.HM_CLEAR if clear else 0, ws.data_ptr(), ws_bytes, _nat.stream_ptr(heatmaps.device))
+        # the workspace is only used by kernels already enqueued on the current stream; the caching
+        # allocator re-issues it stream-ordered, so dropping the reference here is safe
+    _nat.check(status, "draw_heatmap")
+
+
+def draw_heatmap_batched(
+    heatmap: torch.Tensor,
+    centers,
+    radii,
+    diameter_to_sigma_factor: float = 6.0,
+    k_scale: float = 1.0,
+    labels=None,
+    *,
+    clear: bool = False,
+) -> None:
+    """Draw a ragged batch of Gaussians (in place, element-wise max).
+
+    Args:
+        heatmap: float32 ``[B, H, W]`` when ``labels`` is None, else ``[B, C, H, W]``.
+        centers: RaggedBatch (anything with ``.tensor`` and ``.sample_sizes``) int32 ``[B, Nmax, 2]`` (x, y).
+        radii: RaggedBatch int32 ``[B, Nmax]``.
+        diameter_to_sigma_factor: sigma = (2r+1) / factor.
+        k_scale: peak value.
+        labels: optional RaggedBatch int32 ``[B, Nmax]`` of class indices -> one plane per class.
+        clear: (extension) fused zero-fill + draw in one write-only pass.
+
+    Only ``centers.sample_sizes`` decides how many leading objects of a sample are drawn; padded slots are
+    never touched.  Reference: funtions/draw_heatmap_batched.py:27-84 -> draw_heatmap_batched_launcher /
+    draw_heatmap_batched_classwise_launcher (draw_heatmap_cuda.cu:91-165).
+    """
+    centers_t = centers.tensor
+    radii_t = radii.tensor
+    assert centers_t.shape[0] == radii_t.shape[0], "centers and radii must have the same size batch size"
+    assert centers_t.shape[1] == radii_t.shape[1], "centers and radii must have the same maximum number of objects"
+    counts = centers.sample_sizes
+    labels_t: Optional[torch.Tensor] = None
+    if labels is not None:
+        labels_t = labels.tensor
+        assert centers_t.shape[0] == labels_t.shape[0], "centers and labels must have the same size batch size"
+        assert centers_t.shape[1] == labels_t.shape[1], \
+            "centers and labels must have the same maximum number of objects"
+
+    # the reference casts to int32 with an extra kernel on every call (draw_heatmap_batched.py:63);
+    # the C-ABI reads int32 or int64 counts directly
+    if counts.dtype not in (torch.int32, torch.int64):
+        counts = counts.to(torch.int64)
+
+    _check_input(heatmap, "heatmap")
+    _check_input(centers_t, "centers")
+    _check_input(radii_t, "radii")
+    _check_input(counts, "nums_targets")
+    batch = heatmap.size(0)
+    n_max = radii_t.size(1) if radii_t.dim() >= 2 else -1
+    _require(batch == radii_t.size(0) and batch == centers_t.size(0) and batch == counts.size(0),
+             "batch_size (dim 0) need to be the same for all inputs")
+    _require(centers_t.dim() == 3 and centers_t.size(2) == 2, "centers must be of shape [batch_size, num_targets, 2]")
+    _require(radii_t.dim() == 2, "radii must be of shape [batch_size, num_targets]")
+    _require(n_max == centers_t.size(1), "maximum number of targets (dim 1) need to be the same centers and radii")
+    _require(counts.dim() == 1, "nums_targets must be of shape [batch_size]")
+    _check_dtype(heatmap, torch.float32, "heatmap")
+    _check_dtype(centers_t, torch.int32, "centers")
+    _check_dtype(radii_t, torch.int32, "radii")
+    others = [("centers", centers_t), ("radii", radii_t), ("nums_targets", counts)]
+    if labels_t is None:
+        _require(heatmap.dim() == 3, "heatmap must be of shape [batch_size, height, width]")
+        num_classes, (height, width) = 0, heatmap.shape[1:]
+        labels_ptr = None
+    else:
+        _check_input(labels_t, "labels")
+        _require(heatmap.dim() == 4, "heatmap must be of shape [batch_size, max_num_classes, height, width]")
+        _require(labels_t.dim() == 2, "labels must be of shape [batch_size, radii.size(1)]")
+        _require(labels_t.size(0) == batch and labels_t.size(1) == n_max,
+                 "labels shape must be [batch_size, radii.size(1)]")
+        _check_dtype(labels_t, torch.int32, "labels")
+        num_classes, height, width = heatmap.shape[1:]
+        _require(num_classes > 0 or heatmap.numel() == 0, "class-wise heatmap needs at least one class plane")
+        labels_ptr = labels_t.data_ptr()
+        others.append(("labels", labels_t))
+    _same_device(heatmap, *others)
+    if labels_t is not None and num_classes == 0:
+        return
+
+    flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0)
+    with torch.cuda.device(heatmap.device):
+        status = _nat.lib().accv_draw_heatmap_batched_f32(
+            heatmap.data_ptr(), batch, num_classes, height, width, centers_t.data_ptr(), radii_t.data_ptr(),
+            counts.data_ptr(), labels_ptr, n_max, float(diameter_to_sigma_factor), float(k_scale), flags,
+            _nat.stream_ptr(heatmap.device))
+    _nat.check(status, "draw_heatmap_batched")

@@ -1,0 +1,441 @@
+// H1 — Gaussian heat-map rasteriser for gfx950 (MI355X), written as a GATHER-BY-TILE:
+//
+//   * the frame is cut into wave tiles of (32*PX) columns x (2*R) rows; one 64-lane wavefront owns one
+//     tile, lane l holds PX consecutive pixels of rows {i, i+R} (half-wave each) in registers;
+//   * the wave culls the plane's objects against its tile with one __ballot per 64 candidates, compacts the
+//     hits into LDS with a popcount prefix (no atomics, no pre-pass, no workspace for the batched API);
+//   * exp(-(dx^2+dy^2)/var) is evaluated separably: a per-tile LDS table of k*exp(-dy^2/var) per (hit,row)
+//     and PX in-register column factors per hit, so the inner loop is one multiply + one max per pixel;
+//     "outside the object's clipped box" is encoded as NaN in either factor — fmaxf(acc, NaN) == acc —
+//     which reproduces the reference's write extent exactly for any sign of k and any base value;
+//   * max is order independent, so the result is deterministic and equals the reference's atomicMax result;
+//   * each pixel is written exactly once with 16-byte stores (fused-clear mode) or read-max-written once
+//     (in-place mode, only tiles that are touched).
+//
+// Replaces: packages/draw_heatmap/accvlab/draw_heatmap/include/draw_heatmap_cuda_kernel.cuh:26-108 and
+// csrc/draw_heatmap_cuda.cu:29-165 of the reference (one thread per object, serial atomicMax splat).
+// Plane offsets are 64-bit (the reference's are int and overflow for class-wise full-HD batches).
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdint>
+
+#include "accv_common.h"
+
+namespace {
+
+constexpr int kWavesPerGroup = 4;
+constexpr int kCand = 64;  // candidates per cull round = one per lane
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct SplatParams {
+    float* hm;
+    const int32_t* centers;
+    const int32_t* radii;
+    const int32_t* labels;     // class-wise batched only
+    const void* counts;        // batched: i32[B] or i64[B]
+    const int32_t* plane_off;  // flat: [P+1] offsets into obj_list
+    const int32_t* obj_list;   // flat: object ids grouped by plane
+    int H, W;
+    int n_max;      // batched: padded objects per sample
+    int n_classes;  // class-wise: C, else 0
+    int tiles_x, tiles_y;
+    long long n_tiles;
+    float factor, k;
+    int counts_i64;
+};
+
+struct __attribute__((aligned(16))) HitX {  // column side of a hit, read as one ds_read_b128 broadcast
+    int x;
+    float c2;  // log2(e) / var
+    int x0, x1;
+};
+struct __attribute__((aligned(16))) HitY {
+    int y;
+    float c2;
+    int y0, y1;
+};
+
+template <int PX>
+struct Vec;
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+template <>
+struct Vec<4> {
+    using type = vfloat4;
+};
+template <>
+struct Vec<1> {
+    using type = float;
+};
+
+__device__ __forceinline__ float raw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int PX, int R, bool CLEAR, bool NT>
+__global__ __launch_bounds__(kWavesPerGroup * 64) void splat_kernel(const SplatParams p)
+{
+    constexpr int TW = 32 * PX;
+    constexpr int TH = 2 * R;
+    static_assert(R % 4 == 0, "row registers are fetched four at a time");
+
+    __shared__ HitX s_hx[kWavesPerGroup][kCand];
+    __shared__ HitY s_hy[kWavesPerGroup][kCand];
+    __shared__ __attribute__((aligned(16))) float s_ey[kWavesPerGroup][kCand][TH];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long tile = (long long)blockIdx.x * kWavesPerGroup + wave;
+    if (tile >= p.n_tiles) return;  // whole wave exits; waves never synchronise with each other
+
+    const int tx = (int)(tile % p.tiles_x);
+    const long long t2 = tile / p.tiles_x;
+    const int ty = (int)(t2 % p.tiles_y);
+    const long long plane = t2 / p.tiles_y;
+
+    const int tx0 = tx * TW, ty0 = ty * TH;
+    const int tx1 = min(tx0 + TW, p.W), ty1 = min(ty0 + TH, p.H);
+
+    // which objects feed this plane
+    long long obj_base;
+    int n, cls = -1;
+    const bool flat = p.obj_list != nullptr;
+    if (flat) {
+        const int o0 = p.plane_off[plane];
+        obj_base = o0;
+        n = p.plane_off[plane + 1] - o0;
+    } else {
+        long long s = plane;
+        if (p.n_classes > 0) {
+            s = plane / p.n_classes;
+            cls = (int)(plane - s * p.n_classes);
+        }
+        long long cnt = p.counts_i64 ? ((const long long*)p.counts)[s] : (long long)((const int*)p.counts)[s];
+        n = (int)max(0ll, min(cnt, (long long)p.n_max));
+        obj_base = s * p.n_max;
+    }
+
+    const int sub = lane >> 5;         // which half-wave: rows [sub*R, sub*R + R) of the tile
+    const int col0 = tx0 + (lane & 31) * PX;
+
+    float acc[R][PX];
+    const float init = CLEAR ? 0.0f : __builtin_nanf("");
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int c = 0; c < PX; ++c) acc[i][c] = init;
+
+    int total_hits = 0;
+
+    for (int base = 0; base < n; base += kCand) {
+        // ---- cull: one candidate per lane, ballot, popcount-prefix compaction into LDS
+        const int ci = base + lane;
+        bool hit = false;
+        int x = 0, y = 0, r = 0;
+        if (ci < n) {
+            const long long o = flat ? (long long)p.obj_list[obj_base + ci] : obj_base + ci;
+            const int2 cxy = reinterpret_cast<const int2*>(p.centers)[o];
+            x = cxy.x;
+            y = cxy.y;
+            r = p.radii[o];
+            hit = true;
+            if (cls >= 0) hit = p.labels[o] == cls;
+        }
+        // clipped box, exactly the reference's left/right/top/bottom (cuh:64-67, 92-95), in 64-bit
+        const long long x0 = (long long)x - min(x, r), x1 = (long long)x + min((long long)p.W - x, (long long)r + 1);
+        const long long y0 = (long long)y - min(y, r), y1 = (long long)y + min((long long)p.H - y, (long long)r + 1);
+        hit = hit && x1 > x0 && y1 > y0 && x0 < tx1 && x1 > tx0 && y0 < ty1 && y1 > ty0;
+
+        const unsigned long long m = __ballot(hit);
+        const int nh = __popcll(m);
+        if (nh == 0) continue;
+        if (hit) {
+            const int pos = __popcll(m & ((1ull << lane) - 1ull));
+            const float sigma = (float)(2 * r + 1) / p.factor;
+            const float c2 = kLog2e / (2.0f * sigma * sigma);
+            s_hx[wave][pos] = HitX{x, c2, (int)x0, (int)x1};
+            s_hy[wave][pos] = HitY{y, c2, (int)y0, (int)y1};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- row-factor table: ey[h][row] = k * exp(-dy^2/var), NaN outside the clipped rows
+        for (int t = lane; t < nh * TH; t += 64) {
+            const int h = t / TH, rr = t % TH;
+            const HitY hy = s_hy[wave][h];
+            const int row = ty0 + rr;
+            const float d = (float)(row - hy.y);
+            const float v = p.k * raw_exp2(-(d * d) * hy.c2);
+            s_ey[wave][h][rr] = (row >= hy.y0 && row < hy.y1) ? v : __builtin_nanf("");
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- accumulate: per hit PX column factors in registers, row factors from LDS
+        for (int h = 0; h < nh; ++h) {
+            const HitX hx = s_hx[wave][h];
+            float ex[PX];
+#pragma unroll
+            for (int c = 0; c < PX; ++c) {
+                const int col = col0 + c;
+                const float d = (float)(col - hx.x);
+                const float e = raw_exp2(-(d * d) * hx.c2);
+                ex[c] = (col >= hx.x0 && col < hx.x1) ? e : __builtin_nanf("");
+            }
+#pragma unroll
+            for (int q = 0; q < R / 4; ++q) {
+                const float4 e4 = *reinterpret_cast<const float4*>(&s_ey[wave][h][sub * R + 4 * q]);
+                const float ey[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < PX; ++c) acc[4 * q + i][c] = fmaxf(acc[4 * q + i][c], ex[c] * ey[i]);
+            }
+        }
+        total_hits += nh;
+        // the next round overwrites the LDS lists: order it behind this round's reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    if (!CLEAR && total_hits == 0) return;  // in-place: untouched tile costs no HBM traffic
+    if (col0 >= p.W) return;                 // PX == 4 requires W % 4 == 0, so a lane is all-in or all-out
+
+    using V = typename Vec<PX>::type;
+    float* plane_ptr = p.hm + (size_t)plane * (size_t)p.H * (size_t)p.W;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int row = ty0 + sub * R + i;
+        if (row >= p.H) break;
+        V* dst = reinterpret_cast<V*>(plane_ptr + (size_t)row * p.W + col0);
+        V out;
+        if constexpr (PX == 4) {
+            if constexpr (!CLEAR) {
+                const V old = *dst;
+                out = V{fmaxf(old.x, acc[i][0]), fmaxf(old.y, acc[i][1]), fmaxf(old.z, acc[i][2]),
+                        fmaxf(old.w, acc[i][3])};
+            } else {
+                out = V{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+            }
+        } else {
+            if constexpr (!CLEAR)
+                out = fmaxf(*dst, acc[i][0]);
+            else
+                out = acc[i][0];
+        }
+        if constexpr (NT)
+            __builtin_nontemporal_store(out, dst);
+        else
+            *dst = out;
+    }
+}
+
+// ---------------------------------------------------------------- flat API: group objects by plane
+__global__ void bin_count_kernel(const int32_t* __restrict__ idx, int n, int planes, int* __restrict__ cnt)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int pl = idx[i];
+        if (pl >= 0 && pl < planes) atomicAdd(&cnt[pl], 1);
+    }
+}
+
+// single workgroup: exclusive scan of cnt[0..planes) into off[0..planes], cnt reset to 0 (reused as cursor)
+__global__ __launch_bounds__(1024) void bin_scan_kernel(int* __restrict__ cnt, int* __restrict__ off, int planes)
+{
+    __shared__ int s_part[1024];
+    const int t = threadIdx.x;
+    const int per = (planes + 1023) / 1024;
+    const int lo = min(t * per, planes), hi = min(lo + per, planes);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
+    s_part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (t >= d) ? s_part[t - d] : 0;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    int run = s_part[t] - sum;  // exclusive prefix of this thread's chunk
+    for (int i = lo; i < hi; ++i) {
+        const int c = cnt[i];
+        off[i] = run;
+        cnt[i] = 0;
+        run += c;
+    }
+    if (t == 1023) off[planes] = s_part[1023];
+}
+
+__global__ void bin_fill_kernel(const int32_t* __restrict__ idx, int n, int planes, const int* __restrict__ off,
+                                int* __restrict__ cursor, int* __restrict__ list)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int pl = idx[i];
+        if (pl >= 0 && pl < planes) list[off[pl] + atomicAdd(&cursor[pl], 1)] = i;
+    }
+}
+
+__global__ void fill_kernel(float4* __restrict__ dst, size_t n4, float value)
+{
+    const float4 v = make_float4(value, value, value, value);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = v;
+}
+__global__ void fill_tail_kernel(float* __restrict__ dst, size_t n, float value)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+
+template <int PX, int R>
+int launch_splat(SplatParams p, long long planes, bool clear, bool nt, hipStream_t stream)
+{
+    p.tiles_x = (p.W + 32 * PX - 1) / (32 * PX);
+    p.tiles_y = (p.H + 2 * R - 1) / (2 * R);
+    p.n_tiles = planes * p.tiles_x * p.tiles_y;
+    const long long groups = (p.n_tiles + kWavesPerGroup - 1) / kWavesPerGroup;
+    if (groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap: %lld tiles exceed the grid limit", p.n_tiles);
+    if (groups == 0) return ACCV_OK;
+    const dim3 grid((unsigned)groups), block(kWavesPerGroup * 64);
+    if (clear) {
+        if (nt)
+            hipLaunchKernelGGL((splat_kernel<PX, R, true, true>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((splat_kernel<PX, R, true, false>), grid, block, 0, stream, p);
+    } else {
+        if (nt)
+            hipLaunchKernelGGL((splat_kernel<PX, R, false, true>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((splat_kernel<PX, R, false, false>), grid, block, 0, stream, p);
+    }
+    return accv::check_launch("draw_heatmap splat kernel");
+}
+
+int dispatch_splat(const SplatParams& p, long long planes, bool clear, hipStream_t stream)
+{
+    const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.hm) & 15u) == 0);
+    const bool nt = accv::tune_get("hm_nt", 0) != 0;
+    const int rows = accv::tune_get("hm_rows", 8);
+    if (vec4) {
+        if (rows == 16) return launch_splat<4, 16>(p, planes, clear, nt, stream);
+        if (rows == 4) return launch_splat<4, 4>(p, planes, clear, nt, stream);
+        return launch_splat<4, 8>(p, planes, clear, nt, stream);
+    }
+    return launch_splat<1, 8>(p, planes, clear, nt, stream);
+}
+
+int check_common(const void* hm, int h, int w, float factor, const char* who)
+{
+    if (h < 0 || w < 0) return accv::fail(ACCV_EINVAL, "%s: negative heatmap extent %dx%d", who, h, w);
+    if (!hm && (long long)h * w > 0) return accv::fail(ACCV_EINVAL, "%s: heatmap pointer is null", who);
+    (void)factor;
+    return ACCV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t accv_draw_heatmap_flat_workspace_bytes(int num_planes, int num_objects)
+{
+    if (num_planes < 0 || num_objects < 0) return 0;
+    return accv::align_up((size_t)num_planes * 4, 16) + accv::align_up(((size_t)num_planes + 1) * 4, 16) +
+           accv::align_up((size_t)num_objects * 4, 16) + 16;
+}
+
+int accv_draw_heatmap_flat_f32(float* heatmaps, int num_planes, int height, int width, const int32_t* centers,
+                               const int32_t* radii, const int32_t* heatmap_idxes, int num_objects,
+                               float diameter_to_sigma_factor, float k_scale, unsigned flags, void* workspace,
+                               size_t workspace_bytes, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = check_common(heatmaps, height, width, diameter_to_sigma_factor, "draw_heatmap")) return rc;
+    if (num_planes < 0 || num_objects < 0) return accv::fail(ACCV_EINVAL, "draw_heatmap: negative count");
+    const bool clear = (flags & ACCV_HM_CLEAR) != 0;
+    if (num_planes == 0 || height == 0 || width == 0) return ACCV_OK;
+    if (num_objects > 0 && (!centers || !radii || !heatmap_idxes))
+        return accv::fail(ACCV_EINVAL, "draw_heatmap: null object array");
+    if (num_objects == 0 && !clear) return ACCV_OK;
+    const size_t need = accv_draw_heatmap_flat_workspace_bytes(num_planes, num_objects);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15u))
+        return accv::fail(ACCV_EWORKSPACE, "draw_heatmap: workspace needs %zu aligned bytes, got %zu", need,
+                          workspace_bytes);
+
+    char* ws = static_cast<char*>(workspace);
+    int* cnt = reinterpret_cast<int*>(ws);
+    int* off = reinterpret_cast<int*>(ws + accv::align_up((size_t)num_planes * 4, 16));
+    int* list = reinterpret_cast<int*>(reinterpret_cast<char*>(off) + accv::align_up(((size_t)num_planes + 1) * 4, 16));
+
+    if (hipMemsetAsync(cnt, 0, (size_t)num_planes * 4, stream) != hipSuccess)
+        return accv::fail(ACCV_ELAUNCH, "draw_heatmap: memset of the bin counters failed");
+    const int nb = num_objects > 0 ? min((num_objects + 255) / 256, 1024) : 1;
+    if (num_objects > 0) hipLaunchKernelGGL(bin_count_kernel, dim3(nb), dim3(256), 0, stream, heatmap_idxes, num_objects, num_planes, cnt);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, off, num_planes);
+    if (num_objects > 0)
+        hipLaunchKernelGGL(bin_fill_kernel, dim3(nb), dim3(256), 0, stream, heatmap_idxes, num_objects, num_planes, off, cnt, list);
+    if (int rc = accv::check_launch("draw_heatmap binning")) return rc;
+
+    SplatParams p{};
+    p.hm = heatmaps;
+    p.centers = centers;
+    p.radii = radii;
+    p.plane_off = off;
+    p.obj_list = list;
+    p.H = height;
+    p.W = width;
+    p.factor = diameter_to_sigma_factor;
+    p.k = k_scale;
+    return dispatch_splat(p, num_planes, clear, stream);
+}
+
+int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, int height, int width,
+                                  const int32_t* centers, const int32_t* radii, const void* counts,
+                                  const int32_t* labels, int max_num_targets, float diameter_to_sigma_factor,
+                                  float k_scale, unsigned flags, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = check_common(heatmap, height, width, diameter_to_sigma_factor, "draw_heatmap_batched")) return rc;
+    if (batch < 0 || max_num_targets < 0 || num_classes < 0)
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: negative count");
+    if ((num_classes > 0) != (labels != nullptr))
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: labels and num_classes must be given together");
+    if (batch == 0 || height == 0 || width == 0) return ACCV_OK;
+    if (!counts) return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: counts pointer is null");
+    if (max_num_targets > 0 && (!centers || !radii))
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: null object array");
+    const bool clear = (flags & ACCV_HM_CLEAR) != 0;
+    if (max_num_targets == 0 && !clear) return ACCV_OK;
+
+    SplatParams p{};
+    p.hm = heatmap;
+    p.centers = centers;
+    p.radii = radii;
+    p.labels = labels;
+    p.counts = counts;
+    p.H = height;
+    p.W = width;
+    p.n_max = max_num_targets;
+    p.n_classes = num_classes;
+    p.factor = diameter_to_sigma_factor;
+    p.k = k_scale;
+    p.counts_i64 = (flags & ACCV_HM_COUNTS_I64) ? 1 : 0;
+    const long long planes = (long long)batch * (num_classes > 0 ? num_classes : 1);
+    return dispatch_splat(p, planes, clear, stream);
+}
+
+int accv_fill_f32(float* dst, size_t count, float value, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (count == 0) return ACCV_OK;
+    if (!dst) return accv::fail(ACCV_EINVAL, "fill: null pointer");
+    size_t head = 0;
+    while (((reinterpret_cast<uintptr_t>(dst + head)) & 15u) && head < count) ++head;
+    if (head) hipLaunchKernelGGL(fill_tail_kernel, dim3(1), dim3(64), 0, stream, dst, head, value);
+    const size_t n4 = (count - head) / 4;
+    if (n4) {
+        const unsigned blocks = (unsigned)min((n4 + 255) / 256, (size_t)256 * 16);
+        hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<float4*>(dst + head), n4, value);
+    }
+    const size_t tail = count - head - n4 * 4;
+    if (tail) hipLaunchKernelGGL(fill_tail_kernel, dim3(1), dim3(64), 0, stream, dst + head + n4 * 4, tail, value);
+    return accv::check_launch("fill");
+}
+}

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""In-process A/B of splat-kernel variants on the C1 workload (interleaved rounds, one process —
+cdna_hip_programming.md §5.4 rule 24). Prints ms/batch, frames/s and algorithmic GB/s per variant."""
+import argparse
+import itertools
+import os
+import sys
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "accv-lab_amd")]
+
+import bench_workloads as wl  # noqa: E402
+from accvlab import _amd_native as nat  # noqa: E402
+from accvlab.draw_heatmap import draw_heatmap_batched  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--rule", default="A")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--knobs", default="hm_rows=8,16,4;hm_nt=0,1")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    B, H, W = args.batch, 1080, 1920
+    cl, rl = wl.heatmap_objects(B, H, W, 1, 128, args.rule, seed=42)
+    cpad, sizes = wl.pad_ragged(cl)
+    rpad, _ = wl.pad_ragged(rl)
+    c = SimpleNamespace(tensor=cpad.to(dev), sample_sizes=sizes.to(dev))
+    r = SimpleNamespace(tensor=rpad.to(dev), sample_sizes=sizes.to(dev))
+    hm = torch.zeros((B, H, W), device=dev)
+    nbytes = B * H * W * 4
+    knobs = []
+    for part in args.knobs.split(";"):
+        k, vals = part.split("=")
+        knobs.append([(k, int(v)) for v in vals.split(",")])
+    variants = list(itertools.product(*knobs))
+    lib = nat.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.iters
+
+    res = {}
+    for rnd in range(args.rounds):
+        t = timed(lambda: lib.accv_fill_f32(hm.data_ptr(), hm.numel(), 0.0, stream))
+        res.setdefault(("fill",), []).append(t)
+        t = timed(lambda: hm.zero_())
+        res.setdefault(("torch.zero_",), []).append(t)
+        for var in variants:
+            for k, v in var:
+                nat.tune_set(k, v)
+            for mode in ("clear", "inplace"):
+                t = timed(lambda: draw_heatmap_batched(hm, c, r, 6.0, 1.0, clear=(mode == "clear")))
+                res.setdefault(var + (mode,), []).append(t)
+    for key, ts in res.items():
+        ts = sorted(ts)
+        med = ts[len(ts) // 2]
+        print(f"{str(key):60s} median {med:8.4f} ms  min {ts[0]:8.4f} ms  {B / med * 1e3:10.0f} frames/s  "
+              f"{nbytes / med / 1e6:8.1f} GB/s (write-once bytes)")
+
+
+if __name__ == "__main__":
+    main()

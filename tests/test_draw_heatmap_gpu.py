@@ -1,0 +1,285 @@
+"""GPU parity tests of the HIP rasteriser (through the python operator API -> C-ABI) against
+(a) the committed golden vectors of the reference's python oracle and (b) the CPU oracle on seeded inputs.
+
+Tolerance: 1e-5 absolute on fp32 heat-map values (BASELINE.json north_star); the reference's own bar is
+MSE < 1e-3 (packages/draw_heatmap/tests/test_draw_heatmap.py:85)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import bench_workloads as wl
+import h1_cases
+from oracle import h1 as oracle
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+DEV = "cuda:0"
+
+
+def rb(t, sizes):
+    return SimpleNamespace(tensor=t, sample_sizes=sizes)
+
+
+def _dh():
+    from accvlab.draw_heatmap import draw_heatmap, draw_heatmap_batched
+    return draw_heatmap, draw_heatmap_batched
+
+
+def _close(got: torch.Tensor, exp: np.ndarray, what=""):
+    g = got.detach().cpu().numpy()
+    assert g.shape == exp.shape
+    err = float(np.nanmax(np.abs(g.astype(np.float64) - exp.astype(np.float64)))) if g.size else 0.0
+    assert err <= ATOL, f"{what}: max abs err {err}"
+    return err
+
+
+def _flat_from_padded(centers, radii, sizes, labels=None, C=0):
+    cs, rs, idx = [], [], []
+    for s, n in enumerate(sizes.tolist()):
+        cs.append(centers[s, :n])
+        rs.append(radii[s, :n])
+        idx.append(np.full(n, s, dtype=np.int32) if labels is None else (s * C + labels[s, :n]).astype(np.int32))
+    return np.concatenate(cs), np.concatenate(rs), np.concatenate(idx)
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+@pytest.mark.parametrize("gname", ["h1_g1.npz", "h1_g2.npz"])
+@pytest.mark.parametrize("clear", [False, True])
+def test_golden_batched_flat_classwise(gname, clear):
+    draw_heatmap, draw_heatmap_batched = _dh()
+    z = h1_cases.load(gname)
+    k, factor, C = float(z["k"]), float(z["factor"]), int(z["C"])
+    exp = z["expected"]
+    B, H, W = exp.shape
+    centers, radii, sizes, labels = _t(z["centers"]), _t(z["radii"]), _t(z["sizes"]), _t(z["labels"])
+    fill = 123.0 if clear else 0.0  # clear=True must ignore previous content
+    # batched, int64 sample sizes
+    hm = torch.full((B, H, W), fill, device=DEV)
+    draw_heatmap_batched(hm, rb(centers, sizes), rb(radii, sizes), factor, k, clear=clear)
+    _close(hm, exp, "batched")
+    # batched, int32 sample sizes
+    hm = torch.full((B, H, W), fill, device=DEV)
+    draw_heatmap_batched(hm, rb(centers, sizes.to(torch.int32)), rb(radii, sizes), factor, k, clear=clear)
+    _close(hm, exp, "batched i32 sizes")
+    # flat
+    c, r, idx = _flat_from_padded(z["centers"], z["radii"], z["sizes"])
+    hm = torch.full((B, H, W), fill, device=DEV)
+    draw_heatmap(hm, _t(c), _t(r), _t(idx), factor, k, clear=clear)
+    _close(hm, exp, "flat")
+    # class-wise
+    cw = torch.full((B, C, H, W), fill, device=DEV)
+    draw_heatmap_batched(cw, rb(centers, sizes), rb(radii, sizes), factor, k, labels=rb(labels, sizes), clear=clear)
+    if "cw_planes" in z.files:
+        full = np.zeros((B, C, H, W), dtype=np.float32)
+        for (s, cl), e in zip(z["cw_planes"].tolist(), z["cw_expected"]):
+            full[s, cl] = e
+    else:
+        full = z["cw_expected"]
+    _close(cw, full, "class-wise")
+    # flat drawing into B*C planes == class-wise
+    c, r, idx = _flat_from_padded(z["centers"], z["radii"], z["sizes"], z["labels"], C)
+    fl = torch.full((B * C, H, W), fill, device=DEV)
+    draw_heatmap(fl, _t(c), _t(r), _t(idx), factor, k, clear=clear)
+    _close(fl.view(B, C, H, W), full, "flat class planes")
+
+
+@pytest.mark.parametrize("case", list(h1_cases.g3_cases()), ids=lambda c: c[0])
+def test_golden_edge_cases(case):
+    draw_heatmap, draw_heatmap_batched = _dh()
+    name, H, W, c, r, k, factor, base, exp = case
+    n = len(r)
+    hm = torch.full((1, H, W), base, device=DEV)
+    draw_heatmap(hm, _t(c.reshape(-1, 2)), _t(r), torch.zeros(n, dtype=torch.int32, device=DEV), factor, k)
+    _close(hm[0], exp, f"flat {name}")
+    hm = torch.full((1, H, W), base, device=DEV)
+    sizes = torch.tensor([n], device=DEV)
+    draw_heatmap_batched(hm, rb(_t(c.reshape(1, -1, 2)), sizes), rb(_t(r.reshape(1, -1)), sizes), factor, k)
+    _close(hm[0], exp, f"batched {name}")
+    if base == 0.0 and k > 0:
+        hm = torch.full((1, H, W), 9.0, device=DEV)
+        draw_heatmap_batched(hm, rb(_t(c.reshape(1, -1, 2)), sizes), rb(_t(r.reshape(1, -1)), sizes), factor, k,
+                             clear=True)
+        _close(hm[0], exp, f"batched clear {name}")
+
+
+@pytest.mark.parametrize("frame", list(h1_cases.g4_frames()), ids=lambda f: f[0])
+def test_golden_full_hd(frame):
+    _, draw_heatmap_batched = _dh()
+    name, H, W, T, c, r, crc, sums, picks, tiles = frame
+    sizes = torch.tensor([len(r)], device=DEV)
+    hm = torch.empty((1, H, W), device=DEV)
+    draw_heatmap_batched(hm, rb(_t(c[None]), sizes), rb(_t(r[None]), sizes), clear=True)
+    got = hm[0].cpu().numpy()
+    tx = W // T
+    for p, t in zip(picks.tolist(), tiles):
+        i, j = p // tx, p % tx
+        assert np.abs(got[i * T:(i + 1) * T, j * T:(j + 1) * T] - t).max() <= ATOL
+    _, got_sums = h1_cases.tile_crc_and_sums(got, T)
+    # every tile: |sum diff| <= T*T*ATOL, in practice ~1e-4
+    assert np.abs(got_sums - sums).max() <= T * T * ATOL
+    # and the whole frame against the CPU oracle
+    ref = np.zeros((1, H, W), dtype=np.float32)
+    oracle.draw_heatmap_batched(ref, c[None], r[None], np.array([len(r)]), clear=True, threads=8)
+    err = _close(hm, ref, f"full frame {name}")
+    print(f"{name}: max abs err vs oracle {err:.3e}")
+
+
+@pytest.mark.parametrize("H,W,rule", [(1080, 1920, "A"), (270, 480, "A"), (135, 240, "B"), (67, 129, "A"),
+                                      (540, 960, "B")])
+@pytest.mark.parametrize("clear", [False, True])
+def test_random_batches_vs_oracle(H, W, rule, clear):
+    _, draw_heatmap_batched = _dh()
+    B = 6
+    cl, rl = wl.heatmap_objects(B, H, W, 0, 128, rule, seed=H + W)
+    cpad, sizes = wl.pad_ragged(cl, 2)  # padding holds a drawable object at (2,2)
+    rpad, _ = wl.pad_ragged(rl, 3)
+    base = np.random.RandomState(1).rand(B, H, W).astype(np.float32) * 0.3 - 0.1
+    ref = base.copy()
+    oracle.draw_heatmap_batched(ref, cpad.numpy(), rpad.numpy(), sizes.numpy(), k=0.9, clear=clear, threads=8)
+    hm = _t(base)
+    draw_heatmap_batched(hm, rb(cpad.to(DEV), sizes.to(DEV)), rb(rpad.to(DEV), sizes), 6.0, 0.9, clear=clear)
+    _close(hm, ref, f"{H}x{W} rule {rule} clear={clear}")
+
+
+def test_classwise_random_and_bad_labels():
+    _, draw_heatmap_batched = _dh()
+    B, C, H, W = 5, 7, 96, 160
+    cl, rl, ll = wl.heatmap_objects(B, H, W, 0, 40, "A", seed=5, n_classes=C)
+    cpad, sizes = wl.pad_ragged(cl)
+    rpad, _ = wl.pad_ragged(rl, 1)
+    lpad, _ = wl.pad_ragged(ll)
+    if sizes[0] > 1:
+        lpad[0, 0] = -1      # out-of-range labels are ignored (the reference device-asserts)
+        lpad[0, 1] = C + 3
+    ref = np.zeros((B, C, H, W), dtype=np.float32)
+    oracle.draw_heatmap_batched(ref, cpad.numpy(), rpad.numpy(), sizes.numpy(), labels=lpad.numpy())
+    hm = torch.zeros((B, C, H, W), device=DEV)
+    draw_heatmap_batched(hm, rb(cpad.to(DEV), sizes.to(DEV)), rb(rpad.to(DEV), sizes), labels=rb(lpad.to(DEV), sizes))
+    _close(hm, ref, "class-wise random")
+
+
+def test_flat_many_objects_unsorted_and_out_of_range_planes():
+    draw_heatmap, _ = _dh()
+    P, H, W, N = 37, 64, 128, 5000
+    g = np.random.RandomState(3)
+    c = np.stack([g.randint(-5, W + 5, N), g.randint(-5, H + 5, N)], 1).astype(np.int32)
+    r = g.randint(0, 12, N).astype(np.int32)
+    idx = g.randint(-2, P + 2, N).astype(np.int32)
+    ref = np.zeros((P, H, W), dtype=np.float32)
+    oracle.draw_heatmap_flat(ref, c, r, idx, 6.0, 1.0)
+    hm = torch.zeros((P, H, W), device=DEV)
+    draw_heatmap(hm, _t(c), _t(r), _t(idx))
+    _close(hm, ref, "flat many")
+
+
+def test_idempotent_and_monotone():
+    """size-independent properties at BASELINE's full size: drawing twice changes nothing; in-place draw on
+    a zero map equals the fused clear; result >= base everywhere."""
+    _, draw_heatmap_batched = _dh()
+    B, H, W = 8, 1080, 1920
+    cl, rl = wl.heatmap_objects(B, H, W, 1, 128, "A", seed=42)
+    cpad, sizes = wl.pad_ragged(cl)
+    rpad, _ = wl.pad_ragged(rl)
+    c, r = rb(cpad.to(DEV), sizes.to(DEV)), rb(rpad.to(DEV), sizes.to(DEV))
+    a = torch.zeros((B, H, W), device=DEV)
+    draw_heatmap_batched(a, c, r)
+    b = torch.full((B, H, W), -7.0, device=DEV)
+    draw_heatmap_batched(b, c, r, clear=True)
+    assert torch.equal(a, b)
+    a2 = a.clone()
+    draw_heatmap_batched(a2, c, r)
+    assert torch.equal(a, a2)
+    assert float(a.max()) <= 1.0 and float(a.min()) >= 0.0
+    # every object's centre pixel holds exactly k (exp(0) == 1)
+    for s in range(B):
+        n = int(sizes[s])
+        xy = cpad[s, :n].long()
+        ok = (xy[:, 0] >= 0) & (xy[:, 0] < W) & (xy[:, 1] >= 0) & (xy[:, 1] < H)
+        assert torch.all(a[s][xy[ok, 1].to(DEV), xy[ok, 0].to(DEV)] == 1.0)
+
+
+def test_empty_and_degenerate_inputs():
+    draw_heatmap, draw_heatmap_batched = _dh()
+    hm = torch.ones((2, 8, 12), device=DEV)
+    e2 = torch.zeros((0, 2), dtype=torch.int32, device=DEV)
+    e1 = torch.zeros((0,), dtype=torch.int32, device=DEV)
+    draw_heatmap(hm, e2, e1, e1)
+    assert torch.all(hm == 1)
+    draw_heatmap(hm, e2, e1, e1, clear=True)
+    assert torch.all(hm == 0)
+    sizes = torch.zeros(2, dtype=torch.int64, device=DEV)
+    hm = torch.ones((2, 8, 12), device=DEV)
+    draw_heatmap_batched(hm, rb(torch.zeros((2, 0, 2), dtype=torch.int32, device=DEV), sizes),
+                         rb(torch.zeros((2, 0), dtype=torch.int32, device=DEV), sizes))
+    assert torch.all(hm == 1)
+    # zero-sized map
+    draw_heatmap_batched(torch.zeros((2, 0, 12), device=DEV),
+                         rb(torch.zeros((2, 3, 2), dtype=torch.int32, device=DEV), sizes),
+                         rb(torch.zeros((2, 3), dtype=torch.int32, device=DEV), sizes))
+    # unaligned base pointer (odd element offset) falls back to the scalar-store variant
+    big = torch.zeros(1 + 2 * 16 * 64, device=DEV)
+    view = big[1:].view(2, 16, 64)
+    sizes1 = torch.tensor([1, 1], device=DEV)
+    cen = torch.tensor([[[5, 5]], [[60, 10]]], dtype=torch.int32, device=DEV)
+    rad = torch.tensor([[3], [6]], dtype=torch.int32, device=DEV)
+    draw_heatmap_batched(view, rb(cen, sizes1), rb(rad, sizes1))
+    ref = np.zeros((2, 16, 64), dtype=np.float32)
+    oracle.draw_heatmap_batched(ref, cen.cpu().numpy(), rad.cpu().numpy(), np.array([1, 1]))
+    _close(view, ref, "unaligned view")
+    assert float(big[0]) == 0.0
+
+
+def test_error_behaviour_matches_reference():
+    draw_heatmap, draw_heatmap_batched = _dh()
+    hm = torch.zeros((2, 8, 8), device=DEV)
+    c = torch.zeros((3, 2), dtype=torch.int32, device=DEV)
+    r = torch.ones((3,), dtype=torch.int32, device=DEV)
+    i = torch.zeros((3,), dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError):
+        draw_heatmap(hm.cpu(), c, r, i)                     # not a CUDA tensor
+    with pytest.raises(RuntimeError):
+        draw_heatmap(hm.transpose(1, 2), c, r, i)           # not contiguous
+    with pytest.raises(RuntimeError):
+        draw_heatmap(hm, c, r[:2], i)                       # dim0 mismatch
+    with pytest.raises(RuntimeError):
+        draw_heatmap(hm, c.to(torch.int64), r, i)           # wrong dtype
+    with pytest.raises(RuntimeError):
+        draw_heatmap(hm.double(), c, r, i)                  # fp32 only
+    with pytest.raises(RuntimeError):
+        draw_heatmap(hm[0], c, r, i)                        # rank
+    sizes = torch.tensor([1, 1], device=DEV)
+    cb = torch.zeros((2, 3, 2), dtype=torch.int32, device=DEV)
+    rbt = torch.ones((2, 3), dtype=torch.int32, device=DEV)
+    with pytest.raises(AssertionError):
+        draw_heatmap_batched(hm, rb(cb, sizes), rb(rbt[:, :2], sizes))
+    with pytest.raises(AssertionError):
+        draw_heatmap_batched(hm, rb(cb[:1], sizes), rb(rbt, sizes))
+    with pytest.raises(RuntimeError):
+        draw_heatmap_batched(hm[:1], rb(cb, sizes), rb(rbt, sizes))      # batch mismatch
+    with pytest.raises(RuntimeError):
+        draw_heatmap_batched(hm, rb(cb, sizes), rb(rbt, sizes), labels=rb(rbt, sizes))  # needs rank-4 map
+
+
+def test_runs_on_current_stream_without_sync():
+    _, draw_heatmap_batched = _dh()
+    B, H, W = 4, 256, 512
+    cl, rl = wl.heatmap_objects(B, H, W, 1, 64, "A", seed=9)
+    cpad, sizes = wl.pad_ragged(cl)
+    rpad, _ = wl.pad_ragged(rl)
+    ref = np.zeros((B, H, W), dtype=np.float32)
+    oracle.draw_heatmap_batched(ref, cpad.numpy(), rpad.numpy(), sizes.numpy())
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        hm = torch.zeros((B, H, W), device=DEV)
+        c, r = rb(cpad.to(DEV, non_blocking=True), sizes.to(DEV)), rb(rpad.to(DEV), sizes.to(DEV))
+        draw_heatmap_batched(hm, c, r)
+    side.synchronize()
+    _close(hm, ref, "side stream")
