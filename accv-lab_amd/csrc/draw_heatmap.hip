@@ -325,7 +325,7 @@ int dispatch_splat(const SplatParams& p, long long planes, bool clear, hipStream
 int check_common(const void* hm, int h, int w, float factor, const char* who)
 {
     if (h < 0 || w < 0) return accv::fail(ACCV_EINVAL, "%s: negative heatmap extent %dx%d", who, h, w);
-    if (!hm && (long long)h * w > 0) return accv::fail(ACCV_EINVAL, "%s: heatmap pointer is null", who);
+    (void)hm;
     (void)factor;
     return ACCV_OK;
 }
@@ -351,6 +351,7 @@ int accv_draw_heatmap_flat_f32(float* heatmaps, int num_planes, int height, int 
     if (num_planes < 0 || num_objects < 0) return accv::fail(ACCV_EINVAL, "draw_heatmap: negative count");
     const bool clear = (flags & ACCV_HM_CLEAR) != 0;
     if (num_planes == 0 || height == 0 || width == 0) return ACCV_OK;
+    if (!heatmaps) return accv::fail(ACCV_EINVAL, "draw_heatmap: heatmap pointer is null");
     if (num_objects > 0 && (!centers || !radii || !heatmap_idxes))
         return accv::fail(ACCV_EINVAL, "draw_heatmap: null object array");
     if (num_objects == 0 && !clear) return ACCV_OK;
@@ -398,6 +399,7 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
     if ((num_classes > 0) != (labels != nullptr))
         return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: labels and num_classes must be given together");
     if (batch == 0 || height == 0 || width == 0) return ACCV_OK;
+    if (!heatmap) return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: heatmap pointer is null");
     if (!counts) return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: counts pointer is null");
     if (max_num_targets > 0 && (!centers || !radii))
         return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: null object array");
