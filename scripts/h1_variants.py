@@ -24,11 +24,14 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--knobs", default="hm_rows=8,16,4;hm_nt=0,1")
+    ap.add_argument("--empty", action="store_true", help="no objects: isolates the store pattern")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     B, H, W = args.batch, 1080, 1920
     cl, rl = wl.heatmap_objects(B, H, W, 1, 128, args.rule, seed=42)
     cpad, sizes = wl.pad_ragged(cl)
+    if args.empty:
+        sizes = torch.zeros_like(sizes)
     rpad, _ = wl.pad_ragged(rl)
     c = SimpleNamespace(tensor=cpad.to(dev), sample_sizes=sizes.to(dev))
     r = SimpleNamespace(tensor=rpad.to(dev), sample_sizes=sizes.to(dev))
