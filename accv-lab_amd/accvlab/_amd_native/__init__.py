@@ -23,6 +23,8 @@ _f = ctypes.c_float
 _u = ctypes.c_uint
 _sz = ctypes.c_size_t
 _i64 = ctypes.c_int64
+_ll = ctypes.c_longlong
+_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); must list every symbol include/accv_hip.h declares (tests check this)
 SIGNATURES = {
@@ -32,6 +34,15 @@ SIGNATURES = {
     "accv_draw_heatmap_flat_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _u, _vp, _sz, _vp]),
     "accv_draw_heatmap_batched_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _u, _vp]),
     "accv_fill_f32": (_i, [_vp, _sz, _f, _vp]),
+    # H2 ragged kernels
+    "accv_ragged_gather": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp, _vp]),
+    "accv_ragged_scatter": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp, _vp]),
+    "accv_ragged_map_pairs": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp, _vp]),
+    "accv_ragged_insert_const": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _u64, _i, _i, _i, _vp, _vp]),
+    "accv_ragged_pad_fill": (_i, [_vp, _vp, _ll, _ll, _ll, _u64, _i, _i, _vp]),
+    "accv_ragged_accumulate": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _i, _i, _vp, _vp]),
+    "accv_ragged_mask_to_indices": (_i, [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp]),
+    "accv_ragged_pack": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _i, _vp]),
 }
 # not in the public header (bench / profiling knobs)
 _PRIVATE = {

@@ -1,0 +1,52 @@
+"""accvlab.batching_helpers — MI355X-native drop-in for the reference package of the same name
+(public surface: packages/batching_helpers/accvlab/batching_helpers/__init__.py:23-66).
+
+``RaggedBatch`` plus fifteen functions; GPU tensors run hand-written gfx950 kernels from libaccv_hip.so
+(ragged gather / scatter / pair mapping / constant insert / pad fill / ballot compaction / pack), CPU
+tensors use torch.  The reference's private extension modules are available under their original names
+(``batched_indexing_access_cuda``, ``batched_indexing_access_cpu``) with the same functions.
+"""
+from .ragged import RaggedBatch
+from .indexing import (
+    batched_indexing_access,
+    batched_inverse_indexing_access,
+    batched_indexing_write,
+    batched_index_mapping,
+    get_mask_from_indices,
+)
+from .bool_indexing import (
+    batched_bool_indexing,
+    batched_bool_indexing_write,
+    get_compact_from_named_tuple,
+    get_compact_lists,
+    get_indices_from_mask,
+)
+from .packing import (
+    average_over_targets,
+    sum_over_targets,
+    apply_mask_to_tensor,
+    squeeze_except_batch_and_sample,
+    combine_data,
+)
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "__version__",
+    "RaggedBatch",
+    "apply_mask_to_tensor",
+    "average_over_targets",
+    "batched_bool_indexing",
+    "batched_bool_indexing_write",
+    "batched_index_mapping",
+    "batched_indexing_access",
+    "batched_indexing_write",
+    "batched_inverse_indexing_access",
+    "combine_data",
+    "get_compact_from_named_tuple",
+    "get_compact_lists",
+    "get_indices_from_mask",
+    "get_mask_from_indices",
+    "squeeze_except_batch_and_sample",
+    "sum_over_targets",
+]

@@ -1,0 +1,415 @@
+"""Drop-in for the reference's extension module ``accvlab.batching_helpers.batched_indexing_access_cuda``
+(pybind table: cpp_impl/batched_indexing_access_cuda.cpp:247-265): same seven functions, same argument
+names/defaults, same return conventions (new tensors except the ``_in_place`` op), same validation
+(cpp:54-245 with the CHECK_* macros of batched_indexing_access_helpers.h:60-148 -> RuntimeError).
+
+Every function validates on the host, allocates its result with torch (``full`` / ``clone`` exactly
+where the reference does) and enqueues ONE OR TWO kernels of libaccv_hip.so on torch's current stream.
+There is no CPU path in this module (the reference's is CUDA-only too).
+"""
+from __future__ import annotations
+
+import struct
+from typing import Optional, Sequence
+
+import torch
+
+from .. import _amd_native as _nat
+
+_COPY_DTYPES = {torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.int32, torch.int64}
+_ACC_CODE = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3, torch.float16: 4, torch.bfloat16: 5}
+_INDEX_DTYPES = (torch.int32, torch.int64)
+
+
+def _req(cond: bool, msg: str) -> None:
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _contig(t: torch.Tensor, name: str) -> None:
+    _req(t.is_contiguous(), f"{name} must be contiguous")
+
+
+def _same_cuda_device(*named) -> None:
+    name0, first = named[0]
+    _req(first.is_cuda, f"{name0} must be a CUDA tensor")
+    for _, t in named[1:]:
+        _req(t.device == first.device, "All input tensors must be on the same device")
+
+
+def _dims_at_least(t, n, name):
+    if t.numel() != 0:
+        _req(t.dim() >= n, f"{name} must have at least {n} dimensions")
+
+
+def _dims_exact(t, n, name):
+    if t.numel() != 0:
+        _req(t.dim() == n, f"{name} must have {n} dimensions")
+
+
+def _match_first(a, b, n, na, nb_):
+    if a.numel() == 0 and b.numel() == 0:
+        return
+    _req(a.dim() >= n and b.dim() >= n, f"{na} and {nb_} must have at least {n} dimensions")
+    for i in range(n):
+        _req(a.size(i) == b.size(i), f"{na} and {nb_} must have the same size in dimension {i}")
+
+
+def _match_except(a, b, dim, na, nb_):
+    if a.numel() == 0 and b.numel() == 0:
+        return
+    _req(a.dim() == b.dim(), f"{na} and {nb_} must have the same number of dimensions")
+    for i in range(a.dim()):
+        if i != dim:
+            _req(a.size(i) == b.size(i), f"{na} and {nb_} must have the same size in dimension {i}")
+
+
+def _match_all(a, b, na, nb_):
+    if a.numel() == 0 and b.numel() == 0:
+        return
+    _req(a.dim() == b.dim(), f"{na} and {nb_} must have the same number of dimensions")
+    _req(tuple(a.shape) == tuple(b.shape), f"{na} and {nb_} must have the same size")
+
+
+def _index_dtype(t, name) -> int:
+    _req(t.dtype in _INDEX_DTYPES, f"{name}: index tensors must be int32 or int64, got {t.dtype}")
+    return 1 if t.dtype == torch.int64 else 0
+
+
+def _data_dtype(t, name, allow_bool=False) -> None:
+    ok = t.dtype in _COPY_DTYPES or (allow_bool and t.dtype == torch.bool)
+    _req(ok, f"{name}: unsupported data type {t.dtype}")
+
+
+def element_bits(value, dtype: torch.dtype) -> int:
+    """Byte pattern (as an unsigned integer, little endian) of ``value`` converted to ``dtype`` with the
+    conversion rules of ``static_cast<scalar_t>(double)`` used by the reference."""
+    if dtype == torch.float32:
+        return struct.unpack("<I", struct.pack("<f", float(value)))[0]
+    if dtype == torch.float64:
+        return struct.unpack("<Q", struct.pack("<d", float(value)))[0]
+    if dtype == torch.float16:
+        return struct.unpack("<H", struct.pack("<e", float(value)))[0]
+    if dtype == torch.bfloat16:
+        return int(torch.tensor(float(value), dtype=torch.bfloat16).view(torch.int16).item()) & 0xFFFF
+    if dtype == torch.bool:
+        return 1 if value else 0
+    bits = {torch.int8: 8, torch.uint8: 8, torch.int16: 16, torch.int32: 32, torch.int64: 64}.get(dtype)
+    if bits is None:
+        raise RuntimeError(f"unsupported data type {dtype}")
+    return int(value) & ((1 << bits) - 1)
+
+
+def _row_elems(t: torch.Tensor, first_data_dim: int) -> int:
+    n = 1
+    for s in t.shape[first_data_dim:]:
+        n *= int(s)
+    return n
+
+
+def _batch_numel(counts: torch.Tensor) -> int:
+    return int(counts.numel())
+
+
+def _call(status: int, what: str) -> None:
+    _nat.check(status, what)
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------ forward
+def forward(input_data: torch.Tensor, input_indices: torch.Tensor, input_nums_indices: torch.Tensor,
+            fill_value: float = 0.0) -> torch.Tensor:
+    """``res[i, j] = input_data[i, input_indices[i, j]]`` for ``j < input_nums_indices[i]``, ``fill_value``
+    elsewhere (cpp:54-86, kernel cu:52-113 forward direction)."""
+    _contig(input_data, "input_data")
+    _contig(input_indices, "input_indices")
+    _contig(input_nums_indices, "input_nums_indices")
+    _same_cuda_device(("input_data", input_data), ("input_indices", input_indices),
+                      ("input_nums_indices", input_nums_indices))
+    _dims_at_least(input_nums_indices, 1, "input_nums_indices")
+    nb = input_nums_indices.dim()
+    _dims_at_least(input_indices, 1, "input_indices")
+    _dims_at_least(input_data, nb + 1, "input_data")
+    _match_first(input_data, input_indices, nb, "input_data", "input_indices")
+    _match_first(input_indices, input_nums_indices, nb, "input_indices", "input_nums_indices")
+    _req(input_indices.dim() >= nb + 1, f"input_indices must have at least {nb + 1} dimensions")
+    _data_dtype(input_data, "input_data")
+    res_size = list(input_indices.shape[:nb + 1]) + list(input_data.shape[nb + 1:])
+    res = torch.full(res_size, fill_value, dtype=input_data.dtype, device=input_data.device,
+                     requires_grad=input_data.requires_grad)
+    if input_indices.numel() == 0 or res.numel() == 0:
+        return res
+    batch = _batch_numel(input_nums_indices)
+    w_idx = input_indices.size(nb)
+    row_bytes = _row_elems(input_data, nb + 1) * input_data.element_size()
+    with torch.cuda.device(input_data.device):
+        _call(_nat.lib().accv_ragged_gather(
+            input_data.data_ptr(), res.data_ptr(), input_indices.data_ptr(), input_nums_indices.data_ptr(), batch,
+            input_data.size(nb), w_idx, w_idx, row_bytes, _index_dtype(input_indices, "input_indices"),
+            _index_dtype(input_nums_indices, "input_nums_indices"), None, _stream(input_data)), "forward")
+    return res
+
+
+def _scatter_into(res, to_insert, indices, counts, nb, accumulate, clear_first, what):
+    batch = _batch_numel(counts)
+    w_idx = indices.size(nb)
+    elems = _row_elems(to_insert, nb + 1)
+    esz = to_insert.element_size()
+    ii, ci = _index_dtype(indices, "input_indices"), _index_dtype(counts, "input_nums_indices")
+    lib = _nat.lib()
+    with torch.cuda.device(res.device):
+        s = _stream(res)
+        if not accumulate:
+            _call(lib.accv_ragged_scatter(to_insert.data_ptr(), res.data_ptr(), indices.data_ptr(), counts.data_ptr(),
+                                          batch, w_idx, w_idx, res.size(nb), elems * esz, ii, ci, None, s), what)
+        else:
+            _req(to_insert.dtype in _ACC_CODE, f"{what}: accumulation is not supported for {to_insert.dtype}")
+            if clear_first:
+                _call(lib.accv_ragged_insert_const(res.data_ptr(), indices.data_ptr(), counts.data_ptr(), batch, w_idx,
+                                                   w_idx, res.size(nb), elems * esz, 0, esz, ii, ci, None, s), what)
+            _call(lib.accv_ragged_accumulate(to_insert.data_ptr(), res.data_ptr(), None, indices.data_ptr(),
+                                             counts.data_ptr(), batch, w_idx, w_idx, w_idx, res.size(nb), elems,
+                                             _ACC_CODE[to_insert.dtype], ii, ci, None, s), what)
+
+
+def backward_new_tensor(to_insert: torch.Tensor, input_indices: torch.Tensor, input_nums_indices: torch.Tensor,
+                        input_num_targets: int, fill_value: float = 0.0,
+                        backward_accumulate: bool = True) -> torch.Tensor:
+    """Fresh ``full(fill_value)`` tensor of width ``input_num_targets`` with
+    ``res[i, input_indices[i, j]] (+)= to_insert[i, j]`` (cpp:88-120).  With ``backward_accumulate`` several
+    slots pointing at one target are summed (the first write replaces the filler: cu:39-50)."""
+    _contig(to_insert, "to_insert")
+    _contig(input_indices, "input_indices")
+    _contig(input_nums_indices, "input_nums_indices")
+    _same_cuda_device(("to_insert", to_insert), ("input_indices", input_indices),
+                      ("input_nums_indices", input_nums_indices))
+    _dims_at_least(input_nums_indices, 1, "input_nums_indices")
+    nb = input_nums_indices.dim()
+    _dims_at_least(to_insert, nb + 1, "to_insert")
+    _dims_exact(input_indices, nb + 1, "input_indices")
+    _match_first(to_insert, input_indices, nb, "to_insert", "input_indices")
+    _match_first(input_indices, input_nums_indices, nb, "input_indices", "input_nums_indices")
+    _req(to_insert.dim() >= nb + 1, f"to_insert must have at least {nb + 1} dimensions")
+    _data_dtype(to_insert, "to_insert")
+    shape = list(to_insert.shape)
+    shape[nb] = int(input_num_targets)
+    res = torch.full(shape, fill_value, dtype=to_insert.dtype, device=to_insert.device,
+                     requires_grad=to_insert.requires_grad)
+    if input_indices.numel() == 0 or to_insert.numel() == 0 or res.numel() == 0:
+        return res
+    _scatter_into(res, to_insert, input_indices, input_nums_indices, nb, backward_accumulate,
+                  clear_first=(fill_value != 0.0), what="backward_new_tensor")
+    return res
+
+
+def backward_insert(to_insert: torch.Tensor, input_indices: torch.Tensor, input_nums_indices: torch.Tensor,
+                    to_insert_into: torch.Tensor) -> torch.Tensor:
+    """Clone of ``to_insert_into`` with ``res[i, input_indices[i, j]] = to_insert[i, j]`` (cpp:122-146)."""
+    for n, t in (("to_insert", to_insert), ("input_indices", input_indices),
+                 ("input_nums_indices", input_nums_indices), ("to_insert_into", to_insert_into)):
+        _contig(t, n)
+    _same_cuda_device(("to_insert", to_insert), ("input_indices", input_indices),
+                      ("input_nums_indices", input_nums_indices), ("to_insert_into", to_insert_into))
+    _req(to_insert.dtype == to_insert_into.dtype, "Same dtype required for `to_insert` and `to_insert_into`")
+    _dims_at_least(input_nums_indices, 1, "input_nums_indices")
+    nb = input_nums_indices.dim()
+    _dims_at_least(to_insert, nb + 1, "to_insert")
+    _dims_exact(input_indices, nb + 1, "input_indices")
+    _match_first(to_insert, input_indices, nb, "to_insert", "input_indices")
+    _match_first(input_indices, input_nums_indices, nb, "input_indices", "input_nums_indices")
+    _match_except(to_insert, to_insert_into, nb, "to_insert", "to_insert_into")
+    _data_dtype(to_insert, "to_insert")
+    res = to_insert_into.clone()
+    if input_indices.numel() == 0 or to_insert.numel() == 0 or res.numel() == 0:
+        return res
+    _scatter_into(res, to_insert, input_indices, input_nums_indices, nb, False, False, "backward_insert")
+    return res
+
+
+def backward_insert_const(to_insert: float, input_indices: torch.Tensor, input_nums_indices: torch.Tensor,
+                          to_insert_into: torch.Tensor) -> torch.Tensor:
+    """Clone of ``to_insert_into`` with the constant written at the indexed slots (cpp:148-168)."""
+    for n, t in (("input_indices", input_indices), ("input_nums_indices", input_nums_indices),
+                 ("to_insert_into", to_insert_into)):
+        _contig(t, n)
+    _same_cuda_device(("input_indices", input_indices), ("input_nums_indices", input_nums_indices),
+                      ("to_insert_into", to_insert_into))
+    _dims_at_least(input_nums_indices, 1, "input_nums_indices")
+    nb = input_nums_indices.dim()
+    _dims_at_least(to_insert_into, nb + 1, "to_insert_into")
+    _dims_exact(input_indices, nb + 1, "input_indices")
+    _match_first(input_indices, input_nums_indices, nb, "input_indices", "input_nums_indices")
+    _data_dtype(to_insert_into, "to_insert_into")
+    res = to_insert_into.clone()
+    if input_indices.numel() == 0 or res.numel() == 0:
+        return res
+    _insert_const(res, to_insert, input_indices, input_nums_indices, nb, "backward_insert_const")
+    return res
+
+
+def _insert_const(res, value, indices, counts, nb, what):
+    esz = res.element_size()
+    w_idx = indices.size(nb)
+    with torch.cuda.device(res.device):
+        _call(_nat.lib().accv_ragged_insert_const(
+            res.data_ptr(), indices.data_ptr(), counts.data_ptr(), _batch_numel(counts), w_idx, w_idx, res.size(nb),
+            _row_elems(res, nb + 1) * esz, element_bits(value, res.dtype), esz, _index_dtype(indices, "input_indices"),
+            _index_dtype(counts, "input_nums_indices"), None, _stream(res)), what)
+
+
+def map_values_by_index_pairs(input_data: torch.Tensor, input_indices: torch.Tensor, output_indices: torch.Tensor,
+                              nums_indices: torch.Tensor, to_insert_into: torch.Tensor,
+                              backward_accumulate: bool = False) -> torch.Tensor:
+    """Clone of ``to_insert_into`` with ``res[i, output_indices[i, j]] (+)= input_data[i, input_indices[i, j]]``
+    (cpp:170-200, kernel cu:115-160).  Index and count tensors share one integer dtype (cu:462-477)."""
+    for n, t in (("input_data", input_data), ("input_indices", input_indices), ("output_indices", output_indices),
+                 ("nums_indices", nums_indices), ("to_insert_into", to_insert_into)):
+        _contig(t, n)
+    _same_cuda_device(("input_data", input_data), ("input_indices", input_indices),
+                      ("output_indices", output_indices), ("nums_indices", nums_indices),
+                      ("to_insert_into", to_insert_into))
+    _req(input_data.dtype == to_insert_into.dtype, "Same dtype required for `input_data` and `to_insert_into`")
+    _dims_at_least(nums_indices, 1, "nums_indices")
+    nb = nums_indices.dim()
+    _dims_at_least(input_data, nb + 1, "input_data")
+    _dims_exact(input_indices, nb + 1, "input_indices")
+    _dims_exact(output_indices, nb + 1, "output_indices")
+    _match_first(input_data, input_indices, nb, "input_data", "input_indices")
+    _match_all(input_indices, output_indices, "input_indices", "output_indices")
+    _match_first(input_indices, nums_indices, nb, "input_indices", "nums_indices")
+    _match_except(input_data, to_insert_into, nb, "input_data", "to_insert_into")
+    _data_dtype(to_insert_into, "to_insert_into")
+    _req(input_indices.dtype == output_indices.dtype, "input_indices and output_indices must have the same dtype")
+    res = to_insert_into.clone()
+    if input_indices.numel() == 0 or res.numel() == 0 or input_data.numel() == 0:
+        return res
+    ii = _index_dtype(input_indices, "input_indices")
+    ci = _index_dtype(nums_indices, "nums_indices")
+    batch, w_idx = _batch_numel(nums_indices), input_indices.size(nb)
+    elems, esz = _row_elems(res, nb + 1), res.element_size()
+    lib = _nat.lib()
+    with torch.cuda.device(res.device):
+        s = _stream(res)
+        if not backward_accumulate:
+            _call(lib.accv_ragged_map_pairs(input_data.data_ptr(), res.data_ptr(), input_indices.data_ptr(),
+                                            output_indices.data_ptr(), nums_indices.data_ptr(), batch,
+                                            input_data.size(nb), w_idx, w_idx, res.size(nb), elems * esz, ii, ci, None,
+                                            s), "map_values_by_index_pairs")
+        else:
+            _req(res.dtype in _ACC_CODE, f"map_values_by_index_pairs: accumulation is not supported for {res.dtype}")
+            _call(lib.accv_ragged_insert_const(res.data_ptr(), output_indices.data_ptr(), nums_indices.data_ptr(), batch,
+                                               w_idx, w_idx, res.size(nb), elems * esz, 0, esz, ii, ci, None, s),
+                  "map_values_by_index_pairs")
+            _call(lib.accv_ragged_accumulate(input_data.data_ptr(), res.data_ptr(), input_indices.data_ptr(),
+                                             output_indices.data_ptr(), nums_indices.data_ptr(), batch,
+                                             input_data.size(nb), w_idx, w_idx, res.size(nb), elems,
+                                             _ACC_CODE[res.dtype], ii, ci, None, s), "map_values_by_index_pairs")
+    return res
+
+
+def get_mask_from_indices(indices: torch.Tensor, nums_indices: torch.Tensor, num_targets: int) -> torch.Tensor:
+    """bool ``[*batch, num_targets]`` with True at ``indices[i, :nums_indices[i]]`` (cpp:202-228)."""
+    _contig(indices, "indices")
+    _contig(nums_indices, "nums_indices")
+    _same_cuda_device(("indices", indices), ("nums_indices", nums_indices))
+    _dims_at_least(nums_indices, 1, "nums_indices")
+    nb = nums_indices.dim()
+    _dims_exact(indices, nb + 1, "indices")
+    _match_first(indices, nums_indices, nb, "indices", "nums_indices")
+    res = torch.zeros(list(nums_indices.shape) + [int(num_targets)], dtype=torch.bool, device=indices.device)
+    if indices.numel() == 0 or res.numel() == 0:
+        return res
+    _insert_const(res, True, indices, nums_indices, nb, "get_mask_from_indices")
+    return res
+
+
+def set_ragged_batch_padded_to_filler_value_in_place(data: torch.Tensor, nums_valid_entries: torch.Tensor,
+                                                     filler_value: float) -> None:
+    """``data[i, j, ...] = filler_value`` for ``j >= nums_valid_entries[i]``, in place (cpp:230-245)."""
+    _contig(data, "data")
+    _contig(nums_valid_entries, "nums_valid_entries")
+    _same_cuda_device(("data", data), ("nums_valid_entries", nums_valid_entries))
+    _dims_at_least(nums_valid_entries, 1, "nums_valid_entries")
+    nb = nums_valid_entries.dim()
+    _dims_at_least(data, nb + 1, "data")
+    _match_first(data, nums_valid_entries, nb, "data", "nums_valid_entries")
+    _data_dtype(data, "data", allow_bool=True)
+    if data.numel() == 0:
+        return
+    esz = data.element_size()
+    with torch.cuda.device(data.device):
+        _call(_nat.lib().accv_ragged_pad_fill(
+            data.data_ptr(), nums_valid_entries.data_ptr(), _batch_numel(nums_valid_entries), data.size(nb),
+            _row_elems(data, nb + 1) * esz, element_bits(filler_value, data.dtype), esz,
+            _index_dtype(nums_valid_entries, "nums_valid_entries"), _stream(data)),
+            "set_ragged_batch_padded_to_filler_value_in_place")
+
+
+# ------------------------------------------------------------------------------------------------ extensions
+def mask_to_indices(mask: torch.Tensor, valid_counts: Optional[torch.Tensor] = None):
+    """(extension, no reference counterpart in the native layer) positions of the True entries of every row
+    of a 2-D mask, in order, as int64 ``[B, M]`` zero-filled behind, plus int64 counts ``[B]`` — the
+    wave-ballot compaction that replaces torch boolean indexing in batched_bool_indexing."""
+    _req(mask.is_cuda, "mask must be a CUDA tensor")
+    _req(mask.dim() == 2, "mask must be 2-D")
+    m = mask if mask.dtype == torch.bool else mask != 0
+    m = m.contiguous()
+    b, w = m.shape
+    idx = torch.empty((b, w), dtype=torch.int64, device=m.device)
+    sizes = torch.empty((b,), dtype=torch.int64, device=m.device)
+    vc_ptr, vc64 = None, 0
+    if valid_counts is not None:
+        _req(valid_counts.device == m.device and valid_counts.numel() == b, "valid_counts must match the mask rows")
+        valid_counts = valid_counts.contiguous()
+        vc_ptr, vc64 = valid_counts.data_ptr(), _index_dtype(valid_counts, "valid_counts")
+    if b > 0:
+        with torch.cuda.device(m.device):
+            _call(_nat.lib().accv_ragged_mask_to_indices(m.data_ptr(), vc_ptr, vc64, b, w, idx.data_ptr(),
+                                                         sizes.data_ptr(), _stream(m)), "mask_to_indices")
+    return idx, sizes
+
+
+def gather_rows(src: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor, w_idx: int, out: torch.Tensor) -> None:
+    """(extension) ``out[i, j] = src[i, indices[i, j]]`` for j < counts[i], j < w_idx, where ``indices`` may be
+    wider than ``w_idx`` (row stride = indices.size(1)); any dtype incl. bool; single batch dimension."""
+    _req(src.is_contiguous() and out.is_contiguous() and indices.is_contiguous(), "gather_rows: contiguous tensors required")
+    if out.numel() == 0 or w_idx == 0:
+        return
+    row_bytes = _row_elems(src, 2) * src.element_size()
+    with torch.cuda.device(src.device):
+        _call(_nat.lib().accv_ragged_gather(src.data_ptr(), out.data_ptr(), indices.data_ptr(), counts.data_ptr(),
+                                            src.size(0), src.size(1), int(w_idx), indices.size(1), row_bytes,
+                                            _index_dtype(indices, "indices"), _index_dtype(counts, "counts"), None,
+                                            _stream(src)), "gather_rows")
+
+
+def scatter_rows(src: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor, w_idx: int, out: torch.Tensor) -> None:
+    """(extension) ``out[i, indices[i, j]] = src[i, j]`` for j < counts[i], j < w_idx (src width == w_idx)."""
+    _req(src.is_contiguous() and out.is_contiguous() and indices.is_contiguous(), "scatter_rows: contiguous tensors required")
+    if src.numel() == 0 or w_idx == 0:
+        return
+    row_bytes = _row_elems(src, 2) * src.element_size()
+    with torch.cuda.device(src.device):
+        _call(_nat.lib().accv_ragged_scatter(src.data_ptr(), out.data_ptr(), indices.data_ptr(), counts.data_ptr(),
+                                             src.size(0), int(w_idx), indices.size(1), out.size(1), row_bytes,
+                                             _index_dtype(indices, "indices"), _index_dtype(counts, "counts"), None,
+                                             _stream(src)), "scatter_rows")
+
+
+def pack_rows(flat: torch.Tensor, offsets: torch.Tensor, sizes: torch.Tensor, width: int) -> torch.Tensor:
+    """(extension) padded ``[B, width, *inner]`` from ``flat [total, *inner]`` — combine_data on the device."""
+    _req(flat.is_cuda and flat.is_contiguous(), "pack_rows: flat must be a contiguous CUDA tensor")
+    b = sizes.numel()
+    out = torch.empty((b, int(width)) + tuple(flat.shape[1:]), dtype=flat.dtype, device=flat.device)
+    if out.numel() == 0:
+        return out
+    if flat.numel() == 0:
+        return out.zero_()
+    row_bytes = _row_elems(flat, 1) * flat.element_size()
+    with torch.cuda.device(flat.device):
+        _call(_nat.lib().accv_ragged_pack(flat.data_ptr(), out.data_ptr(), offsets.data_ptr(), sizes.data_ptr(), b,
+                                          int(width), row_bytes, 0, _stream(flat)), "pack_rows")
+    return out

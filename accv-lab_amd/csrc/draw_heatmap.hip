@@ -43,6 +43,8 @@ struct SplatParams {
     long long n_tiles;
     float factor, k;
     int counts_i64;
+    int plane_minor;      // tile order: 0 = plane-major (tiles of a plane adjacent), 1 = planes interleaved
+    long long n_planes;
 };
 
 struct __attribute__((aligned(16))) HitX {  // column side of a hit, read as one ds_read_b128 broadcast
@@ -86,10 +88,24 @@ __global__ __launch_bounds__(kWavesPerGroup * 64) void splat_kernel(const SplatP
     const long long tile = (long long)blockIdx.x * kWavesPerGroup + wave;
     if (tile >= p.n_tiles) return;  // whole wave exits; waves never synchronise with each other
 
-    const int tx = (int)(tile % p.tiles_x);
-    const long long t2 = tile / p.tiles_x;
-    const int ty = (int)(t2 % p.tiles_y);
-    const long long plane = t2 / p.tiles_y;
+    int tx, ty;
+    long long plane;
+    if (p.plane_minor) {
+        // groups of kWavesPerGroup column tiles stay together; planes vary fastest across workgroups
+        const long long grp = tile / kWavesPerGroup;
+        const int w = (int)(tile - grp * kWavesPerGroup);
+        plane = grp % p.n_planes;
+        const long long rest = grp / p.n_planes;
+        const int gx = (p.tiles_x + kWavesPerGroup - 1) / kWavesPerGroup;
+        tx = (int)(rest % gx) * kWavesPerGroup + w;
+        ty = (int)(rest / gx);
+        if (tx >= p.tiles_x || ty >= p.tiles_y) return;
+    } else {
+        tx = (int)(tile % p.tiles_x);
+        const long long t2 = tile / p.tiles_x;
+        ty = (int)(t2 % p.tiles_y);
+        plane = t2 / p.tiles_y;
+    }
 
     const int tx0 = tx * TW, ty0 = ty * TH;
     const int tx1 = min(tx0 + TW, p.W), ty1 = min(ty0 + TH, p.H);
@@ -291,20 +307,27 @@ int launch_splat(SplatParams p, long long planes, bool clear, bool nt, hipStream
     p.tiles_x = (p.W + 32 * PX - 1) / (32 * PX);
     p.tiles_y = (p.H + 2 * R - 1) / (2 * R);
     p.n_tiles = planes * p.tiles_x * p.tiles_y;
+    p.n_planes = planes;
+    p.plane_minor = accv::tune_get("hm_order", 0);
+    if (p.plane_minor) {
+        const long long gx = (p.tiles_x + kWavesPerGroup - 1) / kWavesPerGroup;
+        p.n_tiles = planes * gx * kWavesPerGroup * p.tiles_y;
+    }
+    const size_t lds_pad = (size_t)accv::tune_get("hm_lds_pad_kb", 0) * 1024;
     const long long groups = (p.n_tiles + kWavesPerGroup - 1) / kWavesPerGroup;
     if (groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap: %lld tiles exceed the grid limit", p.n_tiles);
     if (groups == 0) return ACCV_OK;
     const dim3 grid((unsigned)groups), block(kWavesPerGroup * 64);
     if (clear) {
         if (nt)
-            hipLaunchKernelGGL((splat_kernel<PX, R, true, true>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((splat_kernel<PX, R, true, true>), grid, block, lds_pad, stream, p);
         else
-            hipLaunchKernelGGL((splat_kernel<PX, R, true, false>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((splat_kernel<PX, R, true, false>), grid, block, lds_pad, stream, p);
     } else {
         if (nt)
-            hipLaunchKernelGGL((splat_kernel<PX, R, false, true>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((splat_kernel<PX, R, false, true>), grid, block, lds_pad, stream, p);
         else
-            hipLaunchKernelGGL((splat_kernel<PX, R, false, false>), grid, block, 0, stream, p);
+            hipLaunchKernelGGL((splat_kernel<PX, R, false, false>), grid, block, lds_pad, stream, p);
     }
     return accv::check_launch("draw_heatmap splat kernel");
 }

@@ -61,6 +61,69 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
                                   const int32_t* labels, int max_num_targets, float diameter_to_sigma_factor,
                                   float k_scale, unsigned flags, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ H2
+ * Ragged-batch kernels (batching_helpers).  Shapes are given after flattening all batch dimensions to
+ * `batch` and all trailing data dimensions to `row_bytes` (= elements per index * element size): the
+ * indexed dimension sits between them.  COPY entry points are dtype-agnostic byte movers (bit-exact).
+ * `indices` is [batch, idx_stride] of int32 (idx_i64 == 0) or int64; only the first `w_idx` slots of a
+ * row are considered and of those only j < counts[i].  Negative indices wrap once; indices still out
+ * of range are skipped and, if `err_counter` (device int*) is non-null, counted there (the reference
+ * device-asserts: batched_indexing_access_cuda_impl.cu:79,143,185).  `counts` is int32 or int64.
+ */
+
+/* dst[i, j, :] = src[i, indices[i,j], :]   — forward of indexing_kernel
+ * (batched_indexing_access_cuda_impl.cu:52-113, host batched_indexing_access_cuda.cpp:54-86).
+ * src [batch, w_src, row], dst [batch, w_idx, row]; dst must be pre-filled by the caller. */
+int accv_ragged_gather(const void* src, void* dst, const void* indices, const void* counts, long long batch,
+                       long long w_src, long long w_idx, long long idx_stride, long long row_bytes, int idx_i64,
+                       int counts_i64, int* err_counter, void* stream);
+
+/* dst[i, indices[i,j], :] = src[i, j, :]   — overwrite direction of indexing_kernel (cpp:88-146 with
+ * backward_accumulate == false).  src [batch, w_idx, row], dst [batch, w_dst, row]. */
+int accv_ragged_scatter(const void* src, void* dst, const void* indices, const void* counts, long long batch,
+                        long long w_idx, long long idx_stride, long long w_dst, long long row_bytes, int idx_i64,
+                        int counts_i64, int* err_counter, void* stream);
+
+/* dst[i, dst_indices[i,j], :] = src[i, src_indices[i,j], :] — map_values_by_index_pairs_kernel
+ * (cu:115-160, cpp:170-200), overwrite mode. */
+int accv_ragged_map_pairs(const void* src, void* dst, const void* src_indices, const void* dst_indices,
+                          const void* counts, long long batch, long long w_src, long long w_idx, long long idx_stride,
+                          long long w_dst, long long row_bytes, int idx_i64, int counts_i64, int* err_counter,
+                          void* stream);
+
+/* dst[i, indices[i,j], :] = const — insert_const_at_indices_kernel (cu:162-194; also builds bool masks,
+ * cpp:202-228).  `elem_bits` holds the element's byte pattern (little endian) of `elem_size` in {1,2,4,8}. */
+int accv_ragged_insert_const(void* dst, const void* indices, const void* counts, long long batch, long long w_idx,
+                             long long idx_stride, long long w_dst, long long row_bytes, uint64_t elem_bits,
+                             int elem_size, int idx_i64, int counts_i64, int* err_counter, void* stream);
+
+/* data[i, j, :] = filler for j >= counts[i] — set_ragged_batch_padded_to_filler_value_kernel
+ * (cu:196-213, cpp:230-245; CPU twin batched_indexing_access_cpu_impl.cpp:27-67). */
+int accv_ragged_pad_fill(void* data, const void* counts, long long batch, long long width, long long row_bytes,
+                         uint64_t elem_bits, int elem_size, int counts_i64, void* stream);
+
+/* dst[i, dst_indices[i,j], k] += src[i, (src_indices ? src_indices[i,j] : j), k] with atomics — the
+ * accumulate mode of indexing_kernel / map_values_by_index_pairs_kernel (cu:39-50, 103-108, 152-156); the
+ * caller clears the touched slots first where "set first, then add" semantics are required.
+ * acc_dtype: 0 f32, 1 f64, 2 i32, 3 i64, 4 f16, 5 bf16;  row_elems = elements per index. */
+int accv_ragged_accumulate(const void* src, void* dst, const void* src_indices_or_null, const void* dst_indices,
+                           const void* counts, long long batch, long long w_src, long long w_idx, long long idx_stride,
+                           long long w_dst, long long row_elems, int acc_dtype, int idx_i64, int counts_i64,
+                           int* err_counter, void* stream);
+
+/* Ragged compaction front end (replaces the torch boolean indexing of batched_bool_indexing.py:195-221 and
+ * batched_processing_py.py:245-268, 577-628): for every row the positions of non-zero mask bytes, in order,
+ * as int64, zero-filled behind; out_sizes[i] = number of hits.  Only the first valid_counts[i] columns are
+ * looked at when valid_counts is given.  out_indices is [batch, width]. */
+int accv_ragged_mask_to_indices(const void* mask_u8, const void* valid_counts_or_null, int valid_i64, long long batch,
+                                long long width, long long* out_indices, long long* out_sizes, void* stream);
+
+/* combine_data / split on device (batched_processing_py.py:410-423, ragged_batch.py:870-934):
+ * unpack == 0: padded[i, j, :] = flat[offsets[i] + j, :] for j < sizes[i], zero bytes elsewhere;
+ * unpack != 0: the inverse copy (flat <- padded, valid entries only).  offsets/sizes are device int64. */
+int accv_ragged_pack(const void* flat, void* padded, const long long* offsets, const long long* sizes, long long batch,
+                     long long width, long long row_bytes, int unpack, void* stream);
+
 /* Streaming fill used by bench.py as the measured write-bandwidth ceiling (not part of the reference API). */
 int accv_fill_f32(float* dst, size_t count, float value, void* stream);
 
