@@ -43,6 +43,16 @@ SIGNATURES = {
     "accv_ragged_accumulate": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _i, _i, _vp, _vp]),
     "accv_ragged_mask_to_indices": (_i, [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp]),
     "accv_ragged_pack": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _i, _vp]),
+    # H3 multi-tensor copier
+    "accv_mtc_plan": (_i, [_ll, _vp, _vp, _vp, _ll, _ll, _vp, _vp, _vp, _vp]),
+    "accv_pinned_acquire": (_vp, [_sz]),
+    "accv_pinned_release": (None, [_vp]),
+    "accv_pinned_trim": (None, []),
+    "accv_pinned_total_bytes": (_sz, []),
+    "accv_mtc_worker_count": (_i, []),
+    "accv_mtc_stage_h2d": (_i, [_ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _i]),
+    "accv_mtc_coalesce": (_i, [_vp, _ll, _vp, _i, _vp]),
+    "accv_memcpy_async": (_i, [_vp, _vp, _sz, _i, _vp]),
 }
 # not in the public header (bench / profiling knobs)
 _PRIVATE = {

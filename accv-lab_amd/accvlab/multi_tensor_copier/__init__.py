@@ -1,0 +1,6 @@
+"""accvlab.multi_tensor_copier — MI355X-native drop-in for the reference package of the same name
+(public surface: packages/multi_tensor_copier/accvlab/multi_tensor_copier/__init__.py:22-28)."""
+from .copier import AsyncCopyHandle, start_copy
+
+__version__ = "0.1.0"
+__all__ = ["__version__", "AsyncCopyHandle", "start_copy"]

@@ -1,0 +1,384 @@
+// H3 — multi-tensor copier, native side (gfx950 / ROCm host runtime).
+//
+//   * accv_mtc_plan:     packs small host tensors into <= max_chunk aligned byte chunks.  Integer-exact restatement
+//                        target: packages/multi_tensor_copier/accvlab/multi_tensor_copier/csrc/multi_tensor_copier.cpp
+//                        :419-433 (bucket key), :481-507 (candidate rule is applied by the caller), :513-549 (offset
+//                        layout), :553-590 (enable only if >= 2 packed).
+//   * pinned arena:      size-class cache over hipHostMalloc — the reference allocates pinned memory per call
+//                        (:597-641); hipHostMalloc is far too slow for that, so buffers are recycled.
+//   * accv_mtc_stage_h2d: parallel memcpy of the leaves into the pinned chunk (the reference's
+//                        fill_cpu_staging_buffers, :647-679) pipelined per chunk with ONE hipMemcpyAsync per chunk
+//                        (enqueue_packed_transfer, :683-730) on the caller-supplied side stream.
+//   * accv_mtc_coalesce: a single device kernel that gathers many small device tensors into one contiguous
+//                        device buffer (no reference counterpart: the reference copies D2H/D2D per tensor,
+//                        :775-820) so that ONE hipMemcpyAsync moves them.
+// No torch types; the python host (accvlab/multi_tensor_copier) owns tensors, streams and events.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "accv_common.h"
+
+namespace {
+
+inline int64_t round_up(int64_t x, int64_t a)
+{
+    if (a <= 1) return x;
+    const int64_t rem = x % a;
+    return rem == 0 ? x : x + (a - rem);
+}
+
+inline int bucket_of(int64_t required_align)  // 16, 8, 4, 2, 1 -> 0..4 (rounded DOWN to the bucket)
+{
+    if (required_align >= 16) return 0;
+    if (required_align >= 8) return 1;
+    if (required_align >= 4) return 2;
+    if (required_align >= 2) return 3;
+    return 4;
+}
+
+// ------------------------------------------------------------------------------------------ worker pool
+class WorkerPool {
+public:
+    static WorkerPool& instance()
+    {
+        static WorkerPool pool;
+        return pool;
+    }
+    int size() const { return (int)workers_.size(); }
+
+    // runs fn(t) for t in [0, tasks) on the pool (the calling thread helps) and waits for completion
+    void parallel(int tasks, const std::function<void(int)>& fn)
+    {
+        if (tasks <= 0) return;
+        if (tasks == 1 || workers_.empty()) {
+            for (int t = 0; t < tasks; ++t) fn(t);
+            return;
+        }
+        auto job = std::make_shared<Job>();
+        job->fn = &fn;
+        job->tasks = tasks;
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            queue_.push_back(job);
+        }
+        cv_.notify_all();
+        run(*job);
+        std::unique_lock<std::mutex> lock(job->done_mutex);
+        job->done_cv.wait(lock, [&] { return job->finished.load() >= job->tasks; });
+        std::lock_guard<std::mutex> qlock(mutex_);
+        queue_.erase(std::remove(queue_.begin(), queue_.end(), job), queue_.end());
+    }
+
+private:
+    struct Job {
+        const std::function<void(int)>* fn;
+        int tasks;
+        std::atomic<int> next{0};
+        std::atomic<int> finished{0};
+        std::mutex done_mutex;
+        std::condition_variable done_cv;
+    };
+
+    WorkerPool()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = (int)std::min<unsigned>(hw ? hw : 1, 16);
+        for (int i = 0; i + 1 < n; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    static void run(Job& job)
+    {
+        for (;;) {
+            const int t = job.next.fetch_add(1);
+            if (t >= job.tasks) break;
+            (*job.fn)(t);
+            if (job.finished.fetch_add(1) + 1 >= job.tasks) {
+                std::lock_guard<std::mutex> lock(job.done_mutex);
+                job.done_cv.notify_all();
+            }
+        }
+    }
+    void loop()
+    {
+        for (;;) {
+            std::shared_ptr<Job> job;
+            {
+                std::unique_lock<std::mutex> lock(mutex_);
+                cv_.wait(lock, [&] {
+                    if (stop_) return true;
+                    for (auto& j : queue_)
+                        if (j->next.load() < j->tasks) return true;
+                    return false;
+                });
+                if (stop_) return;
+                for (auto& j : queue_)
+                    if (j->next.load() < j->tasks) {
+                        job = j;
+                        break;
+                    }
+            }
+            if (job) run(*job);
+        }
+    }
+
+    std::vector<std::thread> workers_;
+    std::vector<std::shared_ptr<Job>> queue_;
+    std::mutex mutex_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+
+// ------------------------------------------------------------------------------------------ pinned arena
+class PinnedArena {
+public:
+    static PinnedArena& instance()
+    {
+        static PinnedArena a;
+        return a;
+    }
+    void* acquire(size_t bytes)
+    {
+        const size_t cls = size_class(bytes);
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            auto it = free_.find(cls);
+            if (it != free_.end() && !it->second.empty()) {
+                void* p = it->second.back();
+                it->second.pop_back();
+                live_[p] = cls;
+                return p;
+            }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, cls, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> lock(mutex_);
+        live_[p] = cls;
+        total_ += cls;
+        return p;
+    }
+    void release(void* p)
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> lock(mutex_);
+        auto it = live_.find(p);
+        if (it == live_.end()) return;
+        free_[it->second].push_back(p);
+        live_.erase(it);
+    }
+    void trim()
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        for (auto& kv : free_)
+            for (void* p : kv.second) {
+                (void)hipHostFree(p);
+                total_ -= kv.first;
+            }
+        free_.clear();
+    }
+    size_t total() const { return total_; }
+
+private:
+    static size_t size_class(size_t bytes)
+    {
+        size_t c = 64 * 1024;
+        while (c < bytes) c <<= 1;  // powers of two from 64 KiB: at most 2x slack, few distinct classes
+        return c;
+    }
+    std::mutex mutex_;
+    std::map<size_t, std::vector<void*>> free_;
+    std::map<void*, size_t> live_;
+    size_t total_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------ device coalescing kernel
+struct CopyItem {
+    const void* src;
+    long long dst_offset;
+    long long nbytes;
+};
+
+// one workgroup per item (grid-stride over items); 16-byte vectors when both sides are 16-byte aligned
+__global__ __launch_bounds__(256) void coalesce_kernel(const CopyItem* __restrict__ items, long long n_items,
+                                                       unsigned char* __restrict__ packed, int scatter)
+{
+    for (long long it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const CopyItem d = items[it];
+        const unsigned char* s = scatter ? packed + d.dst_offset : static_cast<const unsigned char*>(d.src);
+        unsigned char* o = scatter ? const_cast<unsigned char*>(static_cast<const unsigned char*>(d.src)) : packed + d.dst_offset;
+        const bool vec = (((uintptr_t)s | (uintptr_t)o) & 15u) == 0;
+        long long done = 0;
+        if (vec) {
+            const long long n16 = d.nbytes >> 4;
+            const uint4* s4 = reinterpret_cast<const uint4*>(s);
+            uint4* o4 = reinterpret_cast<uint4*>(o);
+            for (long long i = threadIdx.x; i < n16; i += blockDim.x) o4[i] = s4[i];
+            done = n16 << 4;
+        }
+        for (long long i = done + threadIdx.x; i < d.nbytes; i += blockDim.x) o[i] = s[i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int accv_mtc_plan(long long n, const long long* nbytes, const int* elem_size, const unsigned char* candidate,
+                  long long min_align, long long max_chunk_bytes, long long* out_offset, long long* out_chunk,
+                  long long* out_chunk_sizes, long long* out_num_chunks)
+{
+    if (n < 0 || !out_num_chunks) return accv::fail(ACCV_EINVAL, "mtc_plan: bad arguments");
+    *out_num_chunks = 0;
+    if (n == 0) return ACCV_OK;
+    if (!nbytes || !elem_size || !candidate || !out_offset || !out_chunk || !out_chunk_sizes)
+        return accv::fail(ACCV_EINVAL, "mtc_plan: null array");
+    min_align = std::max<long long>(1, min_align);
+    std::vector<long long> order[5];
+    std::vector<long long> req(n, 1);
+    for (long long i = 0; i < n; ++i) {
+        out_offset[i] = -1;
+        out_chunk[i] = -1;
+        if (!candidate[i]) continue;
+        const long long es = std::max(1, elem_size[i]);
+        req[i] = round_up(std::max<long long>(min_align, es), es);
+        order[bucket_of(req[i])].push_back(i);
+    }
+    long long cursor = 0, chunk = 0, packed = 0, n_chunks = 0;
+    for (int b = 0; b < 5; ++b) {
+        for (long long i : order[b]) {
+            long long at = round_up(cursor, req[i]);
+            if (at + nbytes[i] > max_chunk_bytes && cursor > 0) {
+                out_chunk_sizes[n_chunks++] = cursor;
+                cursor = 0;
+                ++chunk;
+                at = 0;
+            }
+            out_offset[i] = at;
+            out_chunk[i] = chunk;
+            cursor = at + nbytes[i];
+            ++packed;
+        }
+    }
+    if (cursor > 0) out_chunk_sizes[n_chunks++] = cursor;
+    if (packed < 2 || n_chunks == 0) {  // packing a single tensor buys nothing
+        for (long long i = 0; i < n; ++i) {
+            out_offset[i] = -1;
+            out_chunk[i] = -1;
+        }
+        n_chunks = 0;
+    }
+    *out_num_chunks = n_chunks;
+    return ACCV_OK;
+}
+
+void* accv_pinned_acquire(size_t bytes)
+{
+    void* p = PinnedArena::instance().acquire(bytes ? bytes : 1);
+    if (!p) accv::fail(ACCV_ERUNTIME, "pinned arena: hipHostMalloc(%zu) failed", bytes);
+    return p;
+}
+
+void accv_pinned_release(void* p) { PinnedArena::instance().release(p); }
+
+void accv_pinned_trim(void) { PinnedArena::instance().trim(); }
+
+size_t accv_pinned_total_bytes(void) { return PinnedArena::instance().total(); }
+
+int accv_mtc_worker_count(void) { return WorkerPool::instance().size() + 1; }
+
+/* Host staging + transfer.  For every chunk c (in order): memcpy the items with chunk_of[i] == c into
+ * staging[c] + offset[i] using up to `threads` workers, then hipMemcpyAsync(device[c], staging[c], chunk_bytes[c])
+ * host->device on `stream`.  Items must be grouped so that item_begin[c]..item_begin[c+1] index `order`.
+ * device[c] == NULL skips the transfer (staging only).  Does not synchronise the stream. */
+int accv_mtc_stage_h2d(long long n_items, const void* const* src, const long long* nbytes, const long long* offset,
+                       const long long* order, long long n_chunks, const long long* item_begin, void* const* staging,
+                       void* const* device, const long long* chunk_bytes, void* stream_, int threads)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_items < 0 || n_chunks < 0) return accv::fail(ACCV_EINVAL, "mtc_stage_h2d: negative count");
+    if (n_chunks == 0) return ACCV_OK;
+    if (!src || !nbytes || !offset || !order || !item_begin || !staging || !device || !chunk_bytes)
+        return accv::fail(ACCV_EINVAL, "mtc_stage_h2d: null array");
+    WorkerPool& pool = WorkerPool::instance();
+    threads = std::max(1, std::min(threads > 0 ? threads : pool.size() + 1, pool.size() + 1));
+    for (long long c = 0; c < n_chunks; ++c) {
+        const long long lo = item_begin[c], hi = item_begin[c + 1];
+        if (lo < 0 || hi < lo || hi > n_items) return accv::fail(ACCV_EINVAL, "mtc_stage_h2d: bad item range");
+        char* base = static_cast<char*>(staging[c]);
+        if (!base && hi > lo) return accv::fail(ACCV_EINVAL, "mtc_stage_h2d: null staging buffer");
+        long long bytes = 0;
+        for (long long k = lo; k < hi; ++k) bytes += nbytes[order[k]];
+        // split the item range into `tasks` pieces of roughly equal bytes
+        int tasks = (int)std::min<long long>(threads, std::max<long long>(1, bytes / (256 * 1024)));
+        tasks = (int)std::min<long long>(tasks, std::max<long long>(1, hi - lo));
+        std::vector<long long> cut(tasks + 1, hi);
+        cut[0] = lo;
+        if (tasks > 1) {
+            long long acc = 0, next = 1;
+            for (long long k = lo; k < hi && next < tasks; ++k) {
+                acc += nbytes[order[k]];
+                if (acc >= bytes * next / tasks) cut[next++] = k + 1;
+            }
+        }
+        std::function<void(int)> work = [&](int t) {
+            for (long long k = cut[t]; k < cut[t + 1]; ++k) {
+                const long long i = order[k];
+                std::memcpy(base + offset[i], src[i], (size_t)nbytes[i]);
+            }
+        };
+        pool.parallel(tasks, work);
+        if (device[c] && chunk_bytes[c] > 0) {
+            hipError_t e = hipMemcpyAsync(device[c], base, (size_t)chunk_bytes[c], hipMemcpyHostToDevice, stream);
+            if (e != hipSuccess) return accv::fail(ACCV_ELAUNCH, "mtc_stage_h2d: hipMemcpyAsync: %s", hipGetErrorString(e));
+        }
+    }
+    return ACCV_OK;
+}
+
+/* Device-side coalescing: items[k] = {device src pointer, byte offset inside `packed`, nbytes}; `items` must be
+ * readable from the device (device memory or pinned host memory).  scatter == 0 gathers src -> packed + offset,
+ * scatter != 0 copies packed + offset -> src (used to fan a packed buffer out again). */
+int accv_mtc_coalesce(const void* items, long long n_items, void* packed, int scatter, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_items < 0) return accv::fail(ACCV_EINVAL, "mtc_coalesce: negative count");
+    if (n_items == 0) return ACCV_OK;
+    if (!items || !packed) return accv::fail(ACCV_EINVAL, "mtc_coalesce: null pointer");
+    const unsigned grid = (unsigned)std::min<long long>(n_items, 256 * 16);
+    hipLaunchKernelGGL(coalesce_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const CopyItem*>(items), n_items,
+                       static_cast<unsigned char*>(packed), scatter);
+    return accv::check_launch("mtc_coalesce");
+}
+
+/* Thin wrappers so the python host never needs another HIP binding. */
+int accv_memcpy_async(void* dst, const void* src, size_t bytes, int kind, void* stream)
+{
+    hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost
+                    : kind == 3 ? hipMemcpyDeviceToDevice : hipMemcpyDefault;
+    if (bytes == 0) return ACCV_OK;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, k, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return accv::fail(ACCV_ELAUNCH, "memcpy_async: %s", hipGetErrorString(e));
+    return ACCV_OK;
+}
+}

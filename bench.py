@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): heat-map frames/s + achieved HBM GB/s, 1920x1080 fp32, ragged
+N_obj in [1,128] packed by batching_helpers, batch 64 per GPU (configs[1]); frames shard across ranks with
+no data-path collective (weak scaling: every rank draws its own 64-frame batch).
+
+One "step" = one fused clear+draw of the whole batch through the public operator
+``accvlab.draw_heatmap.draw_heatmap_batched(..., clear=True)`` -> C-ABI -> one HIP kernel launch, with the
+object lists already resident in HBM.  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "accv-lab_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+import bench_workloads as wl  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
+H, W = 1080, 1920
+
+
+def cpu_baseline(centers_l, radii_l, batch):
+    """The CPU oracle (oracle/h1_splat.c, a port of the reference semantics — kind 'port') timed on this host's
+    cores over the same batch: bounded sample = one pass over the full 64-frame batch, OpenMP over frames."""
+    import numpy as np
+
+    from oracle import h1 as oracle
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, oracle.max_threads(), batch))
+    cpad, sizes = wl.pad_ragged(centers_l)
+    rpad, _ = wl.pad_ragged(radii_l)
+    hm = np.empty((batch, H, W), dtype=np.float32)
+    c, r, s = cpad.numpy(), rpad.numpy(), sizes.numpy()
+    oracle.draw_heatmap_batched(hm[:2], c[:2], r[:2], s[:2], clear=True, threads=min(2, cores))  # page-in / warm
+    t0 = time.perf_counter()
+    oracle.draw_heatmap_batched(hm, c, r, s, clear=True, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"one fused clear+draw pass over the full {batch}-frame C1 batch (rule A), "
+                      f"{dt:.2f} s wall, OpenMP over frames"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU")
+    ap.add_argument("--rule", default="A", choices=["A", "B"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL; used only for the barrier and the max-over-ranks of the time
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    from accvlab.batching_helpers import combine_data
+    from accvlab.draw_heatmap import draw_heatmap_batched
+
+    B = args.batch
+    centers_l, radii_l = wl.heatmap_objects(B, H, W, 1, 128, args.rule, seed=42 + rank)
+    centers = combine_data(centers_l, device=dev)                       # RaggedBatch i32 [B, Nmax, 2]
+    radii = combine_data(radii_l, device=dev, other_with_same_sample_sizes=centers)
+    n_objects = int(sum(int(r.shape[0]) for r in radii_l))
+    hm = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+
+    def step():
+        draw_heatmap_batched(hm, centers, radii, 6.0, 1.0, clear=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    e0.record()  # same (current) stream the kernel is launched on
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    barrier()
+    t1 = time.perf_counter()
+    wall_ms = (t1 - t0) * 1e3 / args.steps
+    kern_ms = e0.elapsed_time(e1) / args.steps
+    if dist is not None:
+        t = torch.tensor([wall_ms, kern_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall_ms, kern_ms = float(t[0]), float(t[1])
+
+    # secondary, rank 0 only: the reference's exact in-place semantics, and the streaming-write ceiling
+    extra = {}
+    if rank == 0:
+        def timed(fn, iters=50):
+            for _ in range(5):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / iters
+
+        ms_inplace = timed(lambda: draw_heatmap_batched(hm, centers, radii, 6.0, 1.0))
+        ms_zero = timed(lambda: hm.zero_())
+        extra = {"inplace_frames_per_s": B / ms_inplace * 1e3, "inplace_ms": ms_inplace,
+                 "torch_zero_fill_GBps": hm.numel() * 4 / ms_zero / 1e6}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    alg_bytes = B * H * W * 4 + 12 * n_objects + 4 * B  # H*W*4 + 12*N_i + 4 per frame
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "heatmap frames/sec (1920x1080 fp32, ragged N_obj in [1,128], fused clear+draw)",
+        "value": world * B / (wall_ms * 1e-3),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall_ms,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"configs[1]: draw_heatmap_batched 1920x1080, batch {B}/GPU, ragged N_obj in [1,128] "
+                               f"via batching_helpers.combine_data, radius rule {args.rule}, factor 6, k 1, fp32",
+                   "frames_per_gpu": B, "objects_per_gpu": n_objects, "parallelism": f"frame-sharded x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel": "splat_kernel<4,8,clear>", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
+        "secondary": extra,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(centers_l, radii_l, B)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

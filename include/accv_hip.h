@@ -124,6 +124,46 @@ int accv_ragged_mask_to_indices(const void* mask_u8, const void* valid_counts_or
 int accv_ragged_pack(const void* flat, void* padded, const long long* offsets, const long long* sizes, long long batch,
                      long long width, long long row_bytes, int unpack, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ H3
+ * Multi-tensor copier: pack planner, pinned arena, threaded staging + chunked host->device transfer, and a
+ * device-side coalescing kernel.  Tensors, streams and events stay with the caller.
+ */
+
+/* Byte layout of the packed chunks — integer-exact counterpart of compute_pack_plan / layout_packed_offsets
+ * (packages/multi_tensor_copier/accvlab/multi_tensor_copier/csrc/multi_tensor_copier.cpp:419-433, 513-549,
+ * 553-590).  candidate[i] != 0 marks leaves that satisfy make_pack_candidate (:481-507: host tensor, target
+ * is a GPU, contiguous, 0 < bytes <= 262144).  required_align = round_up(max(min_align, elem), elem); buckets
+ * {16,8,4,2,1} are laid out in that order, insertion order inside a bucket; a new chunk starts when
+ * offset + bytes > max_chunk_bytes and the chunk is not empty.  Fewer than 2 packed leaves => nothing is packed
+ * (*out_num_chunks == 0, all offsets -1).  out_chunk_sizes must have room for n entries. Host arrays. */
+int accv_mtc_plan(long long n, const long long* nbytes, const int* elem_size, const unsigned char* candidate,
+                  long long min_align, long long max_chunk_bytes, long long* out_offset, long long* out_chunk,
+                  long long* out_chunk_sizes, long long* out_num_chunks);
+
+/* Pinned (page-locked) host buffers from a size-class cache over hipHostMalloc; replaces the per-call pinned
+ * allocations of allocate_staging_buffers (multi_tensor_copier.cpp:597-641).  acquire returns NULL on failure. */
+void* accv_pinned_acquire(size_t bytes);
+void accv_pinned_release(void* ptr);
+void accv_pinned_trim(void);
+size_t accv_pinned_total_bytes(void);
+int accv_mtc_worker_count(void);
+
+/* fill_cpu_staging_buffers + enqueue_packed_transfer (multi_tensor_copier.cpp:647-679, 683-730): per chunk c,
+ * memcpy src[i] -> staging[c] + offset[i] for i in order[item_begin[c] .. item_begin[c+1]) on up to `threads`
+ * workers, then one hipMemcpyAsync(device[c] <- staging[c], chunk_bytes[c]) on `stream` (skipped when device[c]
+ * is NULL).  All arrays are host memory; src/staging are host pointers, device[c] device pointers. */
+int accv_mtc_stage_h2d(long long n_items, const void* const* src, const long long* nbytes, const long long* offset,
+                       const long long* order, long long n_chunks, const long long* item_begin, void* const* staging,
+                       void* const* device, const long long* chunk_bytes, void* stream, int threads);
+
+/* One kernel that gathers (scatter == 0) many small device tensors into `packed`, or fans `packed` out again
+ * (scatter != 0).  items: array of {const void* ptr; long long offset_in_packed; long long nbytes;} readable by
+ * the device.  New component (the reference copies device tensors one by one, multi_tensor_copier.cpp:775-820). */
+int accv_mtc_coalesce(const void* items, long long n_items, void* packed, int scatter, void* stream);
+
+/* hipMemcpyAsync wrapper: kind 1 = H2D, 2 = D2H, 3 = D2D, anything else = default. */
+int accv_memcpy_async(void* dst, const void* src, size_t bytes, int kind, void* stream);
+
 /* Streaming fill used by bench.py as the measured write-bandwidth ceiling (not part of the reference API). */
 int accv_fill_f32(float* dst, size_t count, float value, void* stream);
 

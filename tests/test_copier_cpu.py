@@ -1,0 +1,104 @@
+"""CPU-only checks for H3: the native pack planner against the oracle and the reference-derived offsets, and the
+host->host paths of start_copy (no GPU involved)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import h3 as oracle
+
+
+def native_plan(nbytes, esizes, cand, min_align, max_chunk):
+    from accvlab import _amd_native as nat
+
+    n = len(nbytes)
+    nb = np.asarray(nbytes, dtype=np.int64)
+    es = np.asarray(esizes, dtype=np.int32)
+    cd = np.asarray(cand, dtype=np.uint8)
+    off = np.empty(n, dtype=np.int64)
+    chk = np.empty(n, dtype=np.int64)
+    csz = np.empty(max(n, 1), dtype=np.int64)
+    k = ctypes.c_longlong(0)
+    rc = nat.lib().accv_mtc_plan(n, nb.ctypes.data, es.ctypes.data, cd.ctypes.data, min_align, max_chunk,
+                                 off.ctypes.data, chk.ctypes.data, csz.ctypes.data, ctypes.addressof(k))
+    assert rc == 0
+    return off.tolist(), chk.tolist(), csz[:k.value].tolist()
+
+
+# the five packable leaves of the reference test, in traversal order: f32[8,4], i64[17], f16[11], c64[9], c128[5]
+REF_LEAVES = ([128, 136, 22, 72, 80], [4, 8, 2, 8, 16])
+
+
+@pytest.mark.parametrize("min_align,offsets,chunk", [
+    (16, [0, 128, 272, 304, 384], 464),
+    (1, [288, 80, 416, 216, 0], 438),      # layout order c128, i64, c64, f32, f16
+    (6, [80, 208, 420, 344, 0], 442),      # c128@0, f32@80, i64@208, c64@344, f16@420
+])
+def test_plan_reference_derived_offsets(min_align, offsets, chunk):
+    nb, es = REF_LEAVES
+    for fn in (oracle.plan, native_plan):
+        off, chk, sizes = fn(nb, es, [1] * 5, min_align, 32 << 20)
+        assert off == offsets and chk == [0] * 5 and sizes == [chunk], fn
+    for o, e in zip(offsets, es):
+        assert o % oracle.required_align(min_align, e) == 0
+
+
+def test_plan_random_native_equals_oracle_and_invariants():
+    g = np.random.RandomState(0)
+    for trial in range(200):
+        n = int(g.randint(0, 60))
+        es = g.choice([1, 2, 4, 8, 16], n).tolist()
+        nb = [int(e * g.randint(1, 3000)) for e in es]
+        cand = (g.rand(n) > 0.2).astype(int).tolist()
+        min_align = int(g.choice([1, 2, 6, 16, 24, 64, 100]))
+        max_chunk = int(g.choice([1 << 12, 1 << 15, 1 << 25]))
+        a = oracle.plan(nb, es, cand, min_align, max_chunk)
+        b = native_plan(nb, es, cand, min_align, max_chunk)
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], trial
+        off, chk, sizes = b
+        spans = {}
+        for i in range(n):
+            if off[i] < 0:
+                continue
+            assert cand[i] and off[i] % oracle.required_align(min_align, es[i]) == 0
+            assert off[i] + nb[i] <= sizes[chk[i]]
+            spans.setdefault(chk[i], []).append((off[i], off[i] + nb[i]))
+        for c, sp in spans.items():
+            sp.sort()
+            assert all(x[1] <= y[0] for x, y in zip(sp, sp[1:])), "overlap"
+            assert sizes[c] <= max_chunk or len(sp) == 1
+        if sum(1 for o in off if o >= 0) == 1:
+            pytest.fail("a single tensor must not be packed")
+
+
+def test_plan_fewer_than_two_candidates_disables_packing():
+    assert native_plan([100], [4], [1], 16, 1 << 20) == ([-1], [-1], [])
+    assert native_plan([100, 50], [4, 2], [1, 0], 16, 1 << 20) == ([-1, -1], [-1, -1], [])
+    assert native_plan([], [], [], 16, 1 << 20) == ([], [], [])
+
+
+def test_start_copy_numpy_to_cpu_and_passthrough():
+    """reference behaviours: tests/test_multi_tensor_copier.py:73-97 (numpy -> CPU tensors) and :100-125 (passthrough
+    identity, container types)."""
+    import accvlab.multi_tensor_copier as mtc
+
+    marker = object()
+    data = [np.arange(12, dtype=np.float32).reshape(3, 4),
+            (np.ones((2, 3), dtype=np.float32), [np.zeros((1,), dtype=np.int64)]),
+            {"k": torch.arange(3), "m": marker, "s": "text", 7: None}]
+    for bg in (True, False):
+        h = mtc.start_copy(data, "cpu", pack_cpu_tensors=False, use_background_thread=bg)
+        out = h.get()
+        assert h.ready() is True
+        assert isinstance(out, list) and isinstance(out[1], tuple) and isinstance(out[1][1], list)
+        assert isinstance(out[0], torch.Tensor) and out[0].device.type == "cpu"
+        torch.testing.assert_close(out[0], torch.from_numpy(data[0]))
+        torch.testing.assert_close(out[1][1][0], torch.from_numpy(data[1][1][0]))
+        assert out[2]["m"] is marker and out[2]["s"] == "text" and out[2][7] is None
+        assert out[2]["k"] is data[2]["k"]          # already on the target device: reused as is
+        assert list(out[2].keys()) == ["k", "m", "s", 7]
+    single = mtc.start_copy(torch.arange(4), "cpu").get()
+    assert isinstance(single, torch.Tensor)
+    with pytest.raises(RuntimeError):
+        mtc.start_copy([torch.zeros(1)], "not-a-device")
