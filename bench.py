@@ -49,12 +49,15 @@ def cpu_baseline(centers_l, radii_l, batch):
     hm = np.empty((batch, H, W), dtype=np.float32)
     c, r, s = cpad.numpy(), rpad.numpy(), sizes.numpy()
     oracle.draw_heatmap_batched(hm[:2], c[:2], r[:2], s[:2], clear=True, threads=min(2, cores))  # page-in / warm
+    passes, dt = 0, 0.0
     t0 = time.perf_counter()
-    oracle.draw_heatmap_batched(hm, c, r, s, clear=True, threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"one fused clear+draw pass over the full {batch}-frame C1 batch (rule A), "
-                      f"{dt:.2f} s wall, OpenMP over frames"}
+    while passes < 16 and dt * cores < 15.0:      # bounded: ~15-30 s of CPU work (cores x wall)
+        oracle.draw_heatmap_batched(hm, c, r, s, clear=True, threads=cores)
+        passes += 1
+        dt = time.perf_counter() - t0
+    return {"value": passes * batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{passes} fused clear+draw passes over the full {batch}-frame C1 batch (rule A), "
+                      f"{dt:.2f} s wall = {dt * cores:.0f} core-seconds, OpenMP over frames"}
 
 
 def main():

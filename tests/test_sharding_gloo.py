@@ -1,0 +1,70 @@
+"""N>1 path on CPU: two gloo ranks shard a batch of frames, "draw" their slice with the CPU oracle (test
+infrastructure standing in for the GPU op), and the optional all-gather must reproduce the single-process result
+frame for frame.  Also covers max-over-ranks and uneven shards."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import bench_workloads as wl
+from accvlab.draw_heatmap.sharding import all_gather_heatmaps, max_over_ranks, shard_range
+from oracle import h1 as oracle
+
+H, W, TOTAL = 40, 64, 5
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _draw(centers_l, radii_l, lo, hi):
+    cpad, sizes = wl.pad_ragged(centers_l[lo:hi])
+    rpad, _ = wl.pad_ragged(radii_l[lo:hi])
+    hm = np.zeros((hi - lo, H, W), dtype=np.float32)
+    oracle.draw_heatmap_batched(hm, cpad.numpy(), rpad.numpy(), sizes.numpy(), clear=True)
+    return torch.from_numpy(hm)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        centers_l, radii_l = wl.heatmap_objects(TOTAL, H, W, 0, 6, "A", seed=3)
+        lo, hi = shard_range(TOTAL, rank, world)
+        local = _draw(centers_l, radii_l, lo, hi)
+        full = all_gather_heatmaps(local, total_frames=TOTAL)
+        slow = max_over_ranks(1.0 + rank)
+        torch.save({"full": full, "slow": slow, "range": (lo, hi)}, os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_properties():
+    for total in (0, 1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            lens = [e - b for b, e in spans]
+            assert max(lens) - min(lens) <= 1
+    assert [shard_range(64, r, 8) for r in (0, 7)] == [(0, 8), (56, 64)]
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def test_two_rank_gloo_sharded_draw_and_gather(tmp_path):
+    world = 2
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    centers_l, radii_l = wl.heatmap_objects(TOTAL, H, W, 0, 6, "A", seed=3)
+    ref = _draw(centers_l, radii_l, 0, TOTAL)
+    outs = [torch.load(os.path.join(str(tmp_path), f"r{r}.pt")) for r in range(world)]
+    assert [o["range"] for o in outs] == [(0, 3), (3, 5)]          # uneven shards exercise the padded gather
+    for o in outs:
+        assert torch.equal(o["full"], ref)
+        assert o["slow"] == 2.0
