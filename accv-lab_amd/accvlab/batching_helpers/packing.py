@@ -11,6 +11,7 @@ from __future__ import annotations
 from collections.abc import Sequence as _Seq
 from typing import List, Optional, Sequence, Tuple, Union
 
+import numpy as np
 import torch
 
 from . import batched_indexing_access_cuda as _ext
@@ -107,26 +108,39 @@ def _build_padded(leaves: List[torch.Tensor], lens: List[int], width: int, proto
     inner = tuple(proto.shape[1:])
     sizes_cpu = torch.tensor(lens, dtype=torch.int64)
     device = torch.device(device)
-    parts = [t[:n].to(dtype=proto.dtype) if t.dtype != proto.dtype else t[:n] for t, n in zip(leaves, lens) if n > 0]
     total = int(sum(lens))
     if total == 0 or width == 0:
         return torch.zeros((b, width) + inner, dtype=proto.dtype, device=device), sizes_cpu
-    needs_grad = any(p.requires_grad for p in parts)
-    same_dev = all(p.device == parts[0].device for p in parts)
-    if not same_dev:
-        parts = [p.to(device) for p in parts]
-    flat = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
-    if flat.device != device:
-        flat = flat.to(device, non_blocking=True)
-    offsets_cpu = torch.cumsum(sizes_cpu, 0) - sizes_cpu
+
+    def norm(t, n):
+        if n == 0:
+            return proto.new_zeros((0,) + inner)
+        if t.shape[0] != n:
+            t = t[:n]
+        return t if t.dtype == proto.dtype else t.to(dtype=proto.dtype)
+
+    needs_grad = any(t.requires_grad for t in leaves)
     if device.type == "cuda" and not needs_grad:
+        parts = [norm(t, n) for t, n in zip(leaves, lens) if n > 0]
+        if any(p.device != parts[0].device for p in parts):
+            parts = [p.to(device) for p in parts]
+        flat = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        if flat.device != device:
+            flat = flat.to(device, non_blocking=True)
+        offsets_cpu = torch.cumsum(sizes_cpu, 0) - sizes_cpu
         meta = torch.stack([offsets_cpu, sizes_cpu]).to(device, non_blocking=True)
         return _ext.pack_rows(flat.contiguous(), meta[0], meta[1], width), sizes_cpu
-    rows = torch.repeat_interleave(torch.arange(b), sizes_cpu)
-    cols = torch.arange(total) - torch.repeat_interleave(offsets_cpu, sizes_cpu)
-    padded = torch.zeros((b, width) + inner, dtype=proto.dtype, device=device)
-    padded = padded.index_put((rows.to(device), cols.to(device)), flat)
-    return padded, sizes_cpu
+    # CPU target, or gradients must flow: cat + ONE index_copy (both differentiable); indices built with numpy
+    parts = [norm(t, n) for t, n in zip(leaves, lens) if n > 0]
+    if any(q.device != device for q in parts):
+        parts = [q.to(device) for q in parts]
+    flat = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+    ln = np.asarray(lens, dtype=np.int64)
+    starts = np.cumsum(ln) - ln
+    dest = np.repeat(np.arange(b, dtype=np.int64) * width - starts, ln) + np.arange(total, dtype=np.int64)
+    padded = torch.zeros((b * width,) + inner, dtype=proto.dtype, device=device)
+    padded = padded.index_copy(0, torch.from_numpy(dest).to(device), flat)
+    return padded.view((b, width) + inner), sizes_cpu
 
 
 def combine_data(data_list: Sequence[Union[Sequence, torch.Tensor]], other_with_same_sample_sizes: RaggedBatch = None,

@@ -139,9 +139,12 @@ class RaggedBatch:
         """bool ``(*batch_shape, max_sample_size)``; built from ``sample_sizes`` on first use."""
         if self._mask is None:
             t = self._tensor
-            ones = torch.ones(*t.shape[:self._num_batch_dims], t.shape[self._non_uniform_dim], dtype=torch.bool,
-                              device=t.device)
-            self._mask = SetPaddedTo.apply(ones, self._sample_sizes, False)
+            n = t.shape[self._non_uniform_dim]
+            if t.device.type == "cuda":
+                ones = torch.ones(*t.shape[:self._num_batch_dims], n, dtype=torch.bool, device=t.device)
+                self._mask = SetPaddedTo.apply(ones, self._sample_sizes, False)   # pad-fill kernel
+            else:
+                self._mask = torch.arange(n) < self._sample_sizes.to("cpu").unsqueeze(-1)
         return self._mask
 
     @property
@@ -397,10 +400,12 @@ class RaggedBatch:
         sizes = src.sample_sizes.reshape(-1).tolist()
         back = self._non_uniform_dim - nb
         flat = data.reshape(-1, *data.shape[nb:]) if nb > 1 else data
+        width = flat.shape[1] if flat.dim() > 1 else 0
 
         leaves = []
-        for i, n in enumerate(sizes):
-            s = flat[i][:n]
+        for s, n in zip(flat.unbind(0), sizes):     # one C++ call for the per-sample views, one narrow each
+            if n != width:
+                s = s.narrow(0, 0, n)
             leaves.append(s.transpose(0, back) if back else s)
 
         def nest(items, shape):

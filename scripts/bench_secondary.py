@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Secondary configs of BASELINE.json (not the headline metric; bench.py owns that):
+
+  C0  batching_helpers pack -> mask -> split on torch-CPU, 64 samples, N in [1,32], (n,4) fp32   [us / op]
+  C2  multi_tensor_copier: 10k mixed fp32/int64 small CPU tensors, nested -> GPU, vs per-tensor .to() and a generic
+      recursive .to()                                                                           [ms / batch, GB/s]
+  C3  multi-scale heat-maps (strides 4/8/16 of a 3840x2160 source), batch 32, bbox -> centre/radius front end
+      + fused clear+draw per scale                                                             [frames/s]
+
+Prints one JSON object per config.  C2/C3 need a GPU; C0 runs anywhere.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "accv-lab_amd")]
+
+import torch  # noqa: E402
+
+import bench_workloads as wl  # noqa: E402
+
+
+def _timeit(fn, warm, iters, sync=None):
+    for _ in range(warm):
+        fn()
+    if sync:
+        sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    if sync:
+        sync()
+    return (time.perf_counter() - t0) / iters
+
+
+def c0():
+    from accvlab.batching_helpers import RaggedBatch, combine_data
+
+    boxes = wl.ragged_boxes(64, 1, 32, seed=0)
+
+    def ours():
+        rb = combine_data(boxes)
+        _ = rb.mask
+        return rb.split()
+
+    def loop_reference_style():
+        # the reference's python structure (one slice-assign per sample; per-sample size read in split),
+        # restated for timing only: batched_processing_py.py:410-427, ragged_batch.py:870-934
+        n = max(b.shape[0] for b in boxes)
+        data = torch.zeros((len(boxes), n, 4))
+        sizes = torch.empty(len(boxes), dtype=torch.int64)
+        for i, b in enumerate(boxes):
+            sizes[i] = b.shape[0]
+            data[i, : b.shape[0]] = b
+        mask = torch.arange(n).unsqueeze(0) < sizes.unsqueeze(1)
+        return [data[i][: sizes[i]] for i in range(len(boxes))], mask
+
+    t_ours = _timeit(ours, 20, 200)
+    t_loop = _timeit(loop_reference_style, 20, 200)
+    print(json.dumps({"config": "C0", "metric": "pack+mask+split, 64 CPU samples (n,4) fp32", "ours_us": t_ours * 1e6,
+                      "per_sample_loop_us": t_loop * 1e6, "speedup": t_loop / t_ours}))
+
+
+def _to_recursive(x, dev):
+    if isinstance(x, torch.Tensor):
+        return x.to(dev, non_blocking=True)
+    if isinstance(x, dict):
+        return {k: _to_recursive(v, dev) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_recursive(v, dev) for v in x)
+    return x
+
+
+def _leaves(x):
+    if isinstance(x, torch.Tensor):
+        return [x]
+    if isinstance(x, dict):
+        return [l for v in x.values() for l in _leaves(v)]
+    if isinstance(x, (list, tuple)):
+        return [l for v in x for l in _leaves(v)]
+    return []
+
+
+def c2(num_tensors):
+    from accvlab.multi_tensor_copier import start_copy
+
+    dev = torch.device("cuda", 0)
+    tree = wl.meta_tensor_tree(num_tensors, seed=0)
+    leaves = _leaves(tree)
+    nbytes = sum(t.numel() * t.element_size() for t in leaves)
+    sync = torch.cuda.synchronize
+
+    def naive():
+        return [t.to(dev) for t in leaves]
+
+    t_naive = _timeit(naive, 3, 10, sync)
+    t_rec = _timeit(lambda: _to_recursive(tree, dev), 3, 10, sync)
+    t_mtc = _timeit(lambda: start_copy(tree, dev).get(), 10, 50, sync)
+    t_mtc_inline = _timeit(lambda: start_copy(tree, dev, use_background_thread=False).get(), 5, 30, sync)
+    # latency hidden behind other work: time only start_copy() itself
+    handles = []
+    t_submit = _timeit(lambda: handles.append(start_copy(tree, dev)), 2, 20)
+    for h in handles:
+        h.get()
+    print(json.dumps({"config": "C2", "tensors": len(leaves), "bytes": nbytes, "per_tensor_to_ms": t_naive * 1e3,
+                      "recursive_to_ms": t_rec * 1e3, "multi_tensor_copier_ms": t_mtc * 1e3,
+                      "multi_tensor_copier_inline_ms": t_mtc_inline * 1e3, "start_copy_call_ms": t_submit * 1e3,
+                      "speedup_vs_per_tensor": t_naive / t_mtc, "speedup_vs_recursive": t_rec / t_mtc,
+                      "effective_GBps": nbytes / t_mtc / 1e9}))
+
+
+def c3():
+    from accvlab.batching_helpers import combine_data
+    from accvlab.draw_heatmap import draw_heatmap_batched
+
+    dev = torch.device("cuda", 0)
+    B, SH, SW = 32, 2160, 3840
+    g = torch.Generator().manual_seed(7)
+    centers_f, boxes_f = [], []
+    for _ in range(B):
+        n = int(torch.randint(1, 129, (1,), generator=g))
+        c = torch.rand(n, 2, generator=g) * torch.tensor([SW, SH])
+        half = torch.rand(n, 4, generator=g) * 400
+        centers_f.append(c)
+        boxes_f.append(torch.cat([c - half[:, :2], c + half[:, 2:]], 1))
+    scales = []
+    for s in (4, 8, 16):
+        # front end of packages/draw_heatmap/tests/_test_helpers.py:20-28: r = max(1, ceil(min edge dist / s)), c = int(c / s)
+        cl, rl = [], []
+        for c, b in zip(centers_f, boxes_f):
+            d = torch.cat([c - b[:, :2], b[:, 2:] - c], 1)
+            r = torch.ceil(d.min(1)[0] / s).to(torch.int32).clamp(min=1)
+            cl.append((c / s).to(torch.int32))
+            rl.append(r)
+        crb = combine_data(cl, device=dev)
+        rrb = combine_data(rl, device=dev, other_with_same_sample_sizes=crb)
+        scales.append((torch.empty((B, SH // s, SW // s), device=dev), crb, rrb))
+
+    def step():
+        for hm, c, r in scales:
+            draw_heatmap_batched(hm, c, r, 6.0, 1.0, clear=True)
+
+    t = _timeit(step, 50, 500, torch.cuda.synchronize)
+    nbytes = sum(hm.numel() * 4 for hm, _, _ in scales)
+    print(json.dumps({"config": "C3", "metric": "multi-scale heat-maps strides 4/8/16 of 3840x2160, batch 32",
+                      "ms_per_batch": t * 1e3, "frames_per_s": B / t, "GBps": nbytes / t / 1e9,
+                      "bytes_per_frame": nbytes // B}))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="C0,C2,C3")
+    ap.add_argument("--tensors", type=int, default=10_000)
+    a = ap.parse_args()
+    which = a.configs.split(",")
+    if "C0" in which:
+        c0()
+    if torch.cuda.is_available():
+        if "C2" in which:
+            c2(a.tensors)
+            c2(528)
+        if "C3" in which:
+            c3()
