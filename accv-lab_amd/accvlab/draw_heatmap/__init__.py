@@ -6,7 +6,7 @@ packages/draw_heatmap/accvlab/draw_heatmap/__init__.py:22-24 of the reference):
 class-wise planes).  Both accept one extra keyword, ``clear=False``: with ``clear=True`` the map is
 overwritten with max(0, splats) in a single write-only pass (fused zero-fill + draw).
 """
-from .ops import draw_heatmap, draw_heatmap_batched
+from .ops import draw_heatmap, draw_heatmap_batched, get_centers_and_radii
 
 __version__ = "0.1.0"
-__all__ = ["__version__", "draw_heatmap", "draw_heatmap_batched"]
+__all__ = ["__version__", "draw_heatmap", "draw_heatmap_batched", "get_centers_and_radii"]

@@ -172,3 +172,37 @@ def draw_heatmap_batched(
             counts.data_ptr(), labels_ptr, n_max, float(diameter_to_sigma_factor), float(k_scale), flags,
             _nat.stream_ptr(heatmap.device))
     _nat.check(status, "draw_heatmap_batched")
+
+
+def get_centers_and_radii(centers, bboxes, out_size_factor: float):
+    """Target-prep front end: float centres ``[..., 2]`` (x, y) and boxes ``[..., 4]`` (x0, y0, x1, y1) in source-image
+    pixels -> ``(centers_int32 [..., 2], radii_int32 [...])`` at the heat-map stride ``out_size_factor``:
+    ``r = max(1, ceil(min(c - top_left, bottom_right - c) / stride))``, ``c = int(c / stride)``.
+
+    Same semantics as the helper the reference's tests and examples use in front of ``draw_heatmap``
+    (packages/draw_heatmap/tests/_test_helpers.py:20-28).  Accepts tensors or RaggedBatch-like objects (then the
+    result shares their sample sizes).  CUDA tensors run one fused kernel; CPU tensors use torch.
+    """
+    ragged = hasattr(centers, "tensor") and hasattr(centers, "create_with_sample_sizes_like_self")
+    c_t = centers.tensor if ragged else centers
+    b_t = bboxes.tensor if hasattr(bboxes, "tensor") else bboxes
+    _require(c_t.shape[-1] == 2 and b_t.shape[-1] == 4 and c_t.shape[:-1] == b_t.shape[:-1],
+             "centers must be [..., 2] and bboxes [..., 4] with equal leading dimensions")
+    if c_t.is_cuda:
+        _require(b_t.device == c_t.device, "centers and bboxes must be on the same device")
+        c32 = c_t.to(torch.float32).contiguous()
+        b32 = b_t.to(torch.float32).contiguous()
+        out_c = torch.empty(c32.shape, dtype=torch.int32, device=c32.device)
+        out_r = torch.empty(c32.shape[:-1], dtype=torch.int32, device=c32.device)
+        with torch.cuda.device(c32.device):
+            _nat.check(_nat.lib().accv_heatmap_targets_from_boxes_f32(
+                c32.data_ptr(), b32.data_ptr(), out_r.numel(), float(out_size_factor), out_c.data_ptr(),
+                out_r.data_ptr(), _nat.stream_ptr(c32.device)), "get_centers_and_radii")
+    else:
+        d = torch.cat([c_t - b_t[..., :2], b_t[..., 2:] - c_t], dim=-1)
+        out_r = torch.ceil(torch.min(d, dim=-1)[0] / out_size_factor).to(torch.int32).clamp_(min=1)
+        out_c = (c_t / out_size_factor).to(torch.int32)
+    if ragged:
+        nu = centers.non_uniform_dim
+        return centers.create_with_sample_sizes_like_self(out_c, nu), centers.create_with_sample_sizes_like_self(out_r, nu)
+    return out_c, out_r

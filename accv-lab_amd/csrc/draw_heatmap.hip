@@ -17,6 +17,7 @@
 // Plane offsets are 64-bit (the reference's are int and overflow for class-wise full-HD batches).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 #include <cstdint>
 
@@ -72,7 +73,7 @@ struct Vec<1> {
 
 __device__ __forceinline__ float raw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <int PX, int R, bool CLEAR, bool NT, int WPG = kWavesPerGroup, int LPR = 32>
+template <int PX, int R, bool CLEAR, int SM, int WPG = kWavesPerGroup, int LPR = 32>
 __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
 {
     constexpr int kWavesPerGroup = WPG;  // shadows the namespace constant inside the kernel
@@ -238,10 +239,36 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
             else
                 out = acc[i][0];
         }
-        if constexpr (NT)
+        if constexpr (SM == 1) {
             __builtin_nontemporal_store(out, dst);
-        else
+        } else if constexpr (SM >= 2 && PX == 4) {
+            // cache-policy experiments: raw buffer store with aux bits (16 = sc1 write-through, 1 = sc0, 2 = nt)
+            constexpr int aux = SM == 2 ? 16 : SM == 3 ? 17 : SM == 4 ? 18 : SM == 5 ? 19 : SM == 6 ? 0 : 2;
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(out, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, aux);
+        } else {
             *dst = out;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- target-prep front end
+// centres/boxes (float, source-image pixels) -> integer centre + radius at an output stride; one fused kernel for
+// the ~8 element-wise torch ops of the reference helper (packages/draw_heatmap/tests/_test_helpers.py:20-28):
+//   r = max(1, int(ceil(min(cx-x0, cy-y0, x1-cx, y1-cy) / stride))),  c = int(c / stride)   (fp32, IEEE division)
+__global__ __launch_bounds__(256) void targets_from_boxes_kernel(const float2* __restrict__ centers,
+                                                                 const float4* __restrict__ boxes, long long n,
+                                                                 float stride, int2* __restrict__ out_centers,
+                                                                 int* __restrict__ out_radii)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 c = centers[i];
+        const float4 b = boxes[i];
+        const float m = fminf(fminf(c.x - b.x, c.y - b.y), fminf(b.z - c.x, b.w - c.y));
+        int r = (int)ceilf(__fdiv_rn(m, stride));
+        if (r < 1) r = 1;
+        out_radii[i] = r;
+        out_centers[i] = make_int2((int)__fdiv_rn(c.x, stride), (int)__fdiv_rn(c.y, stride));
     }
 }
 
@@ -303,7 +330,7 @@ __global__ void fill_tail_kernel(float* __restrict__ dst, size_t n, float value)
 }
 
 template <int PX, int R, int WPG = kWavesPerGroup, int LPR = 32>
-int launch_splat(SplatParams p, long long planes, bool clear, bool nt, hipStream_t stream)
+int launch_splat(SplatParams p, long long planes, bool clear, int nt, hipStream_t stream)
 {
     constexpr int kWavesPerGroup = WPG;
     p.tiles_x = (p.W + LPR * PX - 1) / (LPR * PX);
@@ -320,24 +347,43 @@ int launch_splat(SplatParams p, long long planes, bool clear, bool nt, hipStream
     if (groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap: %lld tiles exceed the grid limit", p.n_tiles);
     if (groups == 0) return ACCV_OK;
     const dim3 grid((unsigned)groups), block(kWavesPerGroup * 64);
-    if (clear) {
-        if (nt)
-            hipLaunchKernelGGL((splat_kernel<PX, R, true, true, WPG, LPR>), grid, block, lds_pad, stream, p);
-        else
-            hipLaunchKernelGGL((splat_kernel<PX, R, true, false, WPG, LPR>), grid, block, lds_pad, stream, p);
+    const int sm = nt;  // store mode: 0 plain, 1 nontemporal, 2 sc1, 3 sc0+sc1, 4 sc1+nt
+#define ACCV_LAUNCH_SM(SMV)                                                                                        \
+    do {                                                                                                           \
+        if (clear)                                                                                                 \
+            hipLaunchKernelGGL((splat_kernel<PX, R, true, SMV, WPG, LPR>), grid, block, lds_pad, stream, p);       \
+        else                                                                                                       \
+            hipLaunchKernelGGL((splat_kernel<PX, R, false, SMV, WPG, LPR>), grid, block, lds_pad, stream, p);      \
+    } while (0)
+    if constexpr (PX == 4 && (WPG == 1 || (WPG == 4 && R == 8 && LPR == 32))) {
+        switch (sm) {
+            case 1: ACCV_LAUNCH_SM(1); break;
+            case 2: ACCV_LAUNCH_SM(2); break;
+            case 3: ACCV_LAUNCH_SM(3); break;
+            case 4: ACCV_LAUNCH_SM(4); break;
+            case 5: ACCV_LAUNCH_SM(5); break;
+            case 6: ACCV_LAUNCH_SM(6); break;
+            case 7: ACCV_LAUNCH_SM(7); break;
+            default: ACCV_LAUNCH_SM(0); break;
+        }
     } else {
-        if (nt)
-            hipLaunchKernelGGL((splat_kernel<PX, R, false, true, WPG, LPR>), grid, block, lds_pad, stream, p);
-        else
-            hipLaunchKernelGGL((splat_kernel<PX, R, false, false, WPG, LPR>), grid, block, lds_pad, stream, p);
+        ACCV_LAUNCH_SM(0);
     }
+#undef ACCV_LAUNCH_SM
     return accv::check_launch("draw_heatmap splat kernel");
 }
 
 int dispatch_splat(const SplatParams& p, long long planes, bool clear, hipStream_t stream)
 {
     const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.hm) & 15u) == 0);
-    const bool nt = accv::tune_get("hm_nt", 0) != 0;
+    // store policy: outputs far larger than L2 + Infinity Cache stream straight to HBM with write-through,
+    // non-temporal stores (measured +2..8 % over write-back, profiles/r01_h1_variants_store_modes*.log); small maps
+    // keep plain stores so that a consumer kernel still finds them in L2.  "hm_nt" overrides (A/B runs).
+    const size_t total_bytes = (size_t)planes * p.H * p.W * sizeof(float);
+    const bool plane_fits_rsrc = (size_t)p.H * p.W * sizeof(float) < ((size_t)1 << 31);
+    int nt = accv::tune_get("hm_nt", -1);
+    if (nt < 0) nt = (total_bytes > ((size_t)128 << 20) && plane_fits_rsrc) ? 4 : 0;
+    if (nt >= 2 && !plane_fits_rsrc) nt = 0;
     const int rows = accv::tune_get("hm_rows", 8);
     const int wpg = accv::tune_get("hm_wpg", kWavesPerGroup);
     if (vec4) {
@@ -457,6 +503,24 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
     p.counts_i64 = (flags & ACCV_HM_COUNTS_I64) ? 1 : 0;
     const long long planes = (long long)batch * (num_classes > 0 ? num_classes : 1);
     return dispatch_splat(p, planes, clear, stream);
+}
+
+int accv_heatmap_targets_from_boxes_f32(const float* centers_xy, const float* boxes_xyxy, long long num_objects,
+                                        float stride, int32_t* out_centers, int32_t* out_radii, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (num_objects < 0) return accv::fail(ACCV_EINVAL, "targets_from_boxes: negative count");
+    if (num_objects == 0) return ACCV_OK;
+    if (!centers_xy || !boxes_xyxy || !out_centers || !out_radii)
+        return accv::fail(ACCV_EINVAL, "targets_from_boxes: null pointer");
+    if ((reinterpret_cast<uintptr_t>(boxes_xyxy) & 15u) || (reinterpret_cast<uintptr_t>(centers_xy) & 7u) ||
+        (reinterpret_cast<uintptr_t>(out_centers) & 7u))
+        return accv::fail(ACCV_EINVAL, "targets_from_boxes: centres need 8-byte and boxes 16-byte alignment");
+    const unsigned grid = (unsigned)std::min<long long>((num_objects + 255) / 256, 4096);
+    hipLaunchKernelGGL(targets_from_boxes_kernel, dim3(grid), dim3(256), 0, stream,
+                       reinterpret_cast<const float2*>(centers_xy), reinterpret_cast<const float4*>(boxes_xyxy),
+                       num_objects, stride, reinterpret_cast<int2*>(out_centers), out_radii);
+    return accv::check_launch("targets_from_boxes");
 }
 
 int accv_fill_f32(float* dst, size_t count, float value, void* stream_)

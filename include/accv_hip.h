@@ -61,6 +61,13 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
                                   const int32_t* labels, int max_num_targets, float diameter_to_sigma_factor,
                                   float k_scale, unsigned flags, void* stream);
 
+/* Target-prep front end: float centres [n,2] (x,y) and boxes [n,4] (x0,y0,x1,y1) in source pixels ->
+ * int32 centres [n,2] = int(c / stride) and radii [n] = max(1, int(ceil(min edge distance / stride))) in ONE kernel.
+ * Semantics of get_centers_and_radii (packages/draw_heatmap/tests/_test_helpers.py:20-28; the DALI path uses
+ * get_center_from_bboxes/get_radii_from_bboxes).  fp32 with IEEE division. */
+int accv_heatmap_targets_from_boxes_f32(const float* centers_xy, const float* boxes_xyxy, long long num_objects,
+                                        float stride, int32_t* out_centers, int32_t* out_radii, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ H2
  * Ragged-batch kernels (batching_helpers).  Shapes are given after flattening all batch dimensions to
  * `batch` and all trailing data dimensions to `row_bytes` (= elements per index * element size): the

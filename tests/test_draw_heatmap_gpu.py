@@ -283,3 +283,36 @@ def test_runs_on_current_stream_without_sync():
         draw_heatmap_batched(hm, c, r)
     side.synchronize()
     _close(hm, ref, "side stream")
+
+
+def test_target_prep_front_end_gpu_bit_exact_and_multi_scale():
+    """Fused bbox -> (centre, radius) kernel: bit-exact against the reference helper's outputs stored in G2, and a
+    C3-style multi-scale run (strides 4/8/16) against the CPU path + oracle."""
+    from accvlab.batching_helpers import RaggedBatch
+    from accvlab.draw_heatmap import draw_heatmap_batched, get_centers_and_radii
+
+    z = h1_cases.load("h1_g2.npz")
+    c, r = get_centers_and_radii(_t(z["centers_f"]), _t(z["boxes_f"]), int(z["stride"]))
+    assert np.array_equal(c.cpu().numpy(), z["centers"]) and np.array_equal(r.cpu().numpy(), z["radii"])
+    g = torch.Generator().manual_seed(5)
+    B, SH, SW = 4, 432, 768
+    cf, bf = [], []
+    for _ in range(B):
+        n = int(torch.randint(0, 40, (1,), generator=g))
+        cc = torch.rand(n, 2, generator=g) * torch.tensor([SW, SH])
+        half = torch.rand(n, 4, generator=g) * 90
+        cf.append(cc)
+        bf.append(torch.cat([cc - half[:, :2], cc + half[:, 2:]], 1))
+    cpad, sizes = wl.pad_ragged(cf)
+    bpad, _ = wl.pad_ragged(bf)
+    crb = RaggedBatch(cpad.to(DEV), sample_sizes=sizes.to(DEV))
+    brb = RaggedBatch(bpad.to(DEV), sample_sizes=sizes.to(DEV))
+    for s in (4, 8, 16):
+        ci, ri = get_centers_and_radii(crb, brb, s)
+        ci_cpu, ri_cpu = get_centers_and_radii(cpad, bpad, s)
+        assert isinstance(ci, RaggedBatch) and torch.equal(ci.tensor.cpu(), ci_cpu) and torch.equal(ri.tensor.cpu(), ri_cpu)
+        hm = torch.empty((B, SH // s, SW // s), device=DEV)
+        draw_heatmap_batched(hm, ci, ri, clear=True)
+        ref = np.zeros((B, SH // s, SW // s), dtype=np.float32)
+        oracle.draw_heatmap_batched(ref, ci_cpu.numpy(), ri_cpu.numpy(), sizes.numpy(), clear=True)
+        _close(hm, ref, f"multi-scale stride {s}")

@@ -91,3 +91,16 @@ def test_threads_and_clear_agree():
     oracle.draw_heatmap_batched(a, z["centers"], z["radii"], z["sizes"], k=0.8, clear=True, threads=4)
     oracle.draw_heatmap_batched(b, z["centers"], z["radii"], z["sizes"], k=0.8, threads=1)
     assert np.array_equal(a, b)
+
+
+def test_target_prep_front_end_cpu_matches_reference_fixture():
+    """get_centers_and_radii (CPU path) against the G2 fixture: float centres/boxes -> the int32 centres/radii the
+    reference helper produced (packages/draw_heatmap/tests/_test_helpers.py:20-28)."""
+    import torch
+
+    from accvlab.draw_heatmap import get_centers_and_radii
+
+    z = h1_cases.load("h1_g2.npz")
+    c, r = get_centers_and_radii(torch.from_numpy(z["centers_f"]), torch.from_numpy(z["boxes_f"]), int(z["stride"]))
+    assert c.dtype == torch.int32 and r.dtype == torch.int32
+    assert np.array_equal(c.numpy(), z["centers"]) and np.array_equal(r.numpy(), z["radii"])
