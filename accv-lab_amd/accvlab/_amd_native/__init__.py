@@ -54,6 +54,9 @@ SIGNATURES = {
     "accv_mtc_stage_h2d": (_i, [_ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _i]),
     "accv_mtc_coalesce": (_i, [_vp, _ll, _vp, _i, _vp]),
     "accv_memcpy_async": (_i, [_vp, _vp, _sz, _i, _vp]),
+    # lane_helpers
+    "accv_polyline_scratch_bytes": (_sz, [_ll, _i, _i]),
+    "accv_polyline_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 # not in the public header (bench / profiling knobs)
 _PRIVATE = {

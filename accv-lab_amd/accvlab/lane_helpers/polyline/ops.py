@@ -1,0 +1,186 @@
+"""Batched polyline interpolation / lengths — same four functions, argument meaning and validation as the reference
+(packages/lane_helpers/accvlab/lane_helpers/polyline/functions.py:27-111 over ext_impl/polyline/src/polyline.cpp:101-398).
+
+CUDA tensors run ONE kernel of libaccv_hip.so per call (accv_polyline_sample); CPU tensors use a vectorised torch
+implementation that accumulates in float64 (the reference's CPU path accumulates in at::acc_type, polyline_cpu.cpp).
+"""
+from __future__ import annotations
+
+import torch
+
+from ... import _amd_native as _nat
+
+_DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.float16: 2, torch.bfloat16: 3}
+
+
+def _req(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_points(points, name="points"):
+    _req(isinstance(points, torch.Tensor), f"{name} must be a tensor")
+    _req(points.device.type in ("cpu", "cuda"), f"{name} must be a CPU or CUDA tensor")
+    ok = points.dtype in _DTYPE_CODE if points.is_cuda else points.dtype in (torch.float32, torch.float64)
+    _req(ok, f"{name} has an unsupported dtype {points.dtype}")
+
+
+def _check_sizes(sizes, limit, name):
+    _req(sizes.dtype in (torch.int32, torch.int64), f"{name} must be int32 or int64")
+    _req(sizes.dim() == 1, f"{name} must be a 1D tensor")
+
+
+def _gpu(points, distances, p_sizes, d_sizes, relative, want_points, want_lengths):
+    lib = _nat.lib()
+    b, pmax, dims = points.shape
+    qmax = distances.shape[1] if distances is not None else 0
+    code = _DTYPE_CODE[points.dtype]
+    out_p = torch.empty((b, qmax, dims), dtype=points.dtype, device=points.device) if want_points else None
+    out_l = torch.empty((b,), dtype=points.dtype, device=points.device) if want_lengths else None
+    if b == 0 or (want_points and not want_lengths and (qmax == 0 or dims == 0)):
+        return out_p, out_l
+    points = points.contiguous()
+    distances = distances.contiguous() if distances is not None else None
+    c64 = 0
+    if p_sizes is not None:
+        p_sizes = p_sizes.contiguous()
+        c64 = 1 if p_sizes.dtype == torch.int64 else 0
+    if d_sizes is not None:
+        d_sizes = d_sizes.contiguous()
+    with torch.cuda.device(points.device):
+        sb = lib.accv_polyline_scratch_bytes(b, pmax, code)
+        scratch = torch.empty(sb, dtype=torch.uint8, device=points.device) if sb else None
+        _nat.check(lib.accv_polyline_sample(
+            points.data_ptr(), distances.data_ptr() if distances is not None else None,
+            p_sizes.data_ptr() if p_sizes is not None else None, d_sizes.data_ptr() if d_sizes is not None else None,
+            out_p.data_ptr() if out_p is not None else None, out_l.data_ptr() if out_l is not None else None, b, pmax,
+            qmax, dims, code, c64, int(bool(relative)), scratch.data_ptr() if scratch is not None else None, sb,
+            _nat.stream_ptr(points.device)), "polyline")
+    return out_p, out_l
+
+
+def _cpu_accum(points, p_sizes):
+    """float64 accumulated distances [B, P] with +inf behind the valid points, and total lengths."""
+    b, pmax, _ = points.shape
+    acc = torch.zeros((b, max(pmax, 1)), dtype=torch.float64)
+    n = torch.full((b,), pmax, dtype=torch.int64) if p_sizes is None else p_sizes.to(torch.int64).clamp(0, pmax)
+    if pmax > 1:
+        seg = torch.linalg.vector_norm(points[:, 1:].double() - points[:, :-1].double(), dim=2)
+        valid = torch.arange(pmax - 1).unsqueeze(0) < (n - 1).unsqueeze(1)
+        acc[:, 1:pmax] = torch.cumsum(seg * valid, dim=1)
+    total = acc.gather(1, (n - 1).clamp(min=0).unsqueeze(1)).squeeze(1)
+    return acc[:, :pmax] if pmax > 0 else acc[:, :0], n, total
+
+
+def _cpu_interpolate(points, distances, p_sizes, d_sizes, relative):
+    b, pmax, dims = points.shape
+    q = distances.shape[1]
+    out = torch.empty((b, q, dims), dtype=points.dtype)
+    if b == 0 or q == 0 or dims == 0:
+        return out
+    acc, n, total = _cpu_accum(points, p_sizes)
+    d = distances.double()
+    if relative:
+        d = d * total.unsqueeze(1)
+    if pmax == 0:
+        return out.fill_(float("nan"))
+    inf_tail = torch.arange(pmax).unsqueeze(0) >= n.unsqueeze(1)
+    keys = acc.masked_fill(inf_tail, float("inf"))
+    idx = torch.searchsorted(keys, d.contiguous(), right=True) - 1            # last index with accum <= d
+    last = (n - 1).clamp(min=0).unsqueeze(1)
+    lo = idx.clamp(min=0).minimum(last)
+    hi = (lo + 1).minimum(last)
+    d0, d1 = acc.gather(1, lo), acc.gather(1, hi)
+    seg = d1 - d0
+    eps = torch.finfo(torch.float64).eps
+    w1 = torch.where(seg >= eps, (d - d0) / seg.clamp(min=eps), torch.zeros_like(d))
+    w1 = torch.where((idx < 0) | (idx >= last), torch.zeros_like(w1), w1)     # clamped to an end point
+    p0 = points.double().gather(1, lo.unsqueeze(-1).expand(b, q, dims))
+    p1 = points.double().gather(1, hi.unsqueeze(-1).expand(b, q, dims))
+    res = p0 * (1.0 - w1).unsqueeze(-1) + p1 * w1.unsqueeze(-1)
+    res = torch.where((w1 == 0).unsqueeze(-1), p0, res)                       # exact end / lower points
+    res = torch.where((n == 0).view(b, 1, 1), torch.full_like(res, float("nan")), res)
+    out.copy_(res)
+    if d_sizes is not None:
+        pass  # entries behind distances.sample_sizes are unspecified padding
+    return out
+
+
+def _cpu_lengths(points, p_sizes):
+    b = points.shape[0]
+    if b == 0:
+        return torch.empty((0,), dtype=points.dtype)
+    _, n, total = _cpu_accum(points, p_sizes)
+    total = torch.where(n == 0, torch.full_like(total, float("nan")), total)
+    return total.to(points.dtype)
+
+
+def interpolate(points: torch.Tensor, distances: torch.Tensor, *, relative: bool = False) -> torch.Tensor:
+    """Sample every polyline of ``points (batch, num_points, num_dims)`` at ``distances (batch, num_distances)`` measured
+    along the polyline from its first point (``relative=True``: as fractions of its total length).  Queries before the
+    start / beyond the end clamp to the first / last point.  Returns ``(batch, num_distances, num_dims)``."""
+    _check_points(points)
+    _check_points(distances, "distances")
+    _req(points.dim() == 3, "points must have shape (batch, num_points, num_dims)")
+    _req(distances.dim() == 2, "distances must have shape (batch, num_distances)")
+    _req(points.size(0) == distances.size(0), "points and distances must contain the same number of polylines")
+    _req(points.dtype == distances.dtype, "points and distances must have the same dtype")
+    _req(points.device == distances.device, "points and distances must be on the same device")
+    if points.is_cuda:
+        return _gpu(points, distances, None, None, relative, True, False)[0]
+    return _cpu_interpolate(points, distances, None, None, relative)
+
+
+def lengths(points: torch.Tensor) -> torch.Tensor:
+    """Total length of every polyline of ``points (batch, num_points, num_dims)`` -> ``(batch,)``."""
+    _check_points(points)
+    _req(points.dim() == 3, "points must have shape (batch, num_points, num_dims)")
+    if points.is_cuda:
+        return _gpu(points, None, None, None, False, False, True)[1]
+    return _cpu_lengths(points, None)
+
+
+def _check_var(points, sizes, name):
+    _check_sizes(sizes, points.size(1), name)
+    _req(sizes.device == points.device, f"{name} must be on the same device as its tensor")
+    _req(sizes.size(0) == points.size(0), f"{name} must contain one count per polyline")
+
+
+def interpolate_var_size_batch(points, distances, *, relative: bool = False):
+    """Ragged variant: ``points`` / ``distances`` are RaggedBatch-like (``(batch, max_num_points, num_dims)`` and
+    ``(batch, max_num_distances)``, one batch dimension, non-uniform dimension 1).  Returns a RaggedBatch with the
+    distances' sample sizes."""
+    assert points.num_batch_dims == 1, "points must have exactly one batch dimension"
+    assert distances.num_batch_dims == 1, "distances must have exactly one batch dimension"
+    assert points.non_uniform_dim == 1, "points.non_uniform_dim must be 1 for shape (batch, max_num_points, num_dims)"
+    assert distances.non_uniform_dim == 1, "distances.non_uniform_dim must be 1 for shape (batch, max_num_distances)"
+    pt, dt, ps, ds = points.tensor, distances.tensor, points.sample_sizes, distances.sample_sizes
+    _check_points(pt)
+    _check_points(dt, "distances")
+    _req(pt.dim() == 3, "points must have shape (batch, max_num_points, num_dims)")
+    _req(dt.dim() == 2, "distances must have shape (batch, max_num_distances)")
+    _req(pt.size(0) == dt.size(0), "points and distances must contain the same number of polylines")
+    _req(pt.dtype == dt.dtype, "points and distances must have the same dtype")
+    _req(pt.device == dt.device, "points and distances must be on the same device")
+    _req(ps.dtype == ds.dtype, "points.sample_sizes and distances.sample_sizes must have the same dtype "
+                               "(both int32 or both int64)")
+    _check_var(pt, ps, "points.sample_sizes")
+    _check_var(dt, ds, "distances.sample_sizes")
+    if pt.is_cuda:
+        res = _gpu(pt, dt, ps, ds, relative, True, False)[0]
+    else:
+        res = _cpu_interpolate(pt, dt, ps, ds, relative)
+    return distances.create_with_sample_sizes_like_self(res)
+
+
+def lengths_var_size_batch(points) -> torch.Tensor:
+    """Total length of every polyline of a ragged batch -> ``(batch,)``."""
+    assert points.num_batch_dims == 1, "points must have exactly one batch dimension"
+    assert points.non_uniform_dim == 1, "points.non_uniform_dim must be 1 for shape (batch, max_num_points, num_dims)"
+    pt, ps = points.tensor, points.sample_sizes
+    _check_points(pt)
+    _req(pt.dim() == 3, "points must have shape (batch, max_num_points, num_dims)")
+    _check_var(pt, ps, "points.sample_sizes")
+    if pt.is_cuda:
+        return _gpu(pt, None, ps, None, False, False, True)[1]
+    return _cpu_lengths(pt, ps)

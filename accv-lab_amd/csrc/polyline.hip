@@ -1,0 +1,265 @@
+// lane_helpers — batched polyline arc-length interpolation and lengths for gfx950.
+//
+// Replaces packages/lane_helpers/ext_impl/polyline/include/polyline_kernels.cuh:390-455 (four kernels) and the host
+// launch logic of src/polyline.cu:59-129; edge semantics follow include/polyline_common.cuh:58-163:
+//   * accum[i] = distance from the first point to point i; query d (x total length when `relative`);
+//   * d before the first point -> first point, d beyond the last -> last point;
+//   * otherwise the segment [i, i+1] with accum[i] <= d is interpolated linearly; a segment shorter than
+//     epsilon(accumulation type) returns its lower point;
+//   * a polyline with zero points yields NaN for every query; lengths: 0 points -> NaN, 1 point -> 0.
+// Design (not a translation): ONE workgroup of 256 threads per polyline; segment lengths are written to LDS by
+// contiguous per-thread chunks, the 256 chunk totals are scanned by one 64-lane wave with __shfl_up (the reference
+// hard-codes 32-lane shuffles, polyline_kernels.cuh:26-35,58-70), then every thread binary-searches its queries in
+// LDS.  Accumulation is fp32 for f32/f16/bf16 storage and fp64 for f64 (the reference GPU path accumulates in the
+// storage dtype, polyline_common.cuh:56-58).  Polylines longer than the LDS budget use a caller-provided global
+// scratch row instead (same code path, pointer swap).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <limits>
+
+#include "accv_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kLdsBudgetBytes = 48 * 1024;
+
+enum PolyType { kPF32 = 0, kPF64 = 1, kPF16 = 2, kPBF16 = 3 };
+
+template <int TY>
+struct Storage;
+template <>
+struct Storage<kPF32> {
+    using T = float;
+    using Acc = float;
+    static __device__ __forceinline__ Acc load(const T* p) { return *p; }
+    static __device__ __forceinline__ void store(T* p, Acc v) { *p = v; }
+    static __device__ __forceinline__ void copy(T* d, const T* s) { *d = *s; }
+};
+template <>
+struct Storage<kPF64> {
+    using T = double;
+    using Acc = double;
+    static __device__ __forceinline__ Acc load(const T* p) { return *p; }
+    static __device__ __forceinline__ void store(T* p, Acc v) { *p = v; }
+    static __device__ __forceinline__ void copy(T* d, const T* s) { *d = *s; }
+};
+template <>
+struct Storage<kPF16> {
+    using T = uint16_t;
+    using Acc = float;
+    static __device__ __forceinline__ Acc load(const T* p) { return (float)(*reinterpret_cast<const _Float16*>(p)); }
+    static __device__ __forceinline__ void store(T* p, Acc v)
+    {
+        _Float16 h = (_Float16)v;
+        *p = *reinterpret_cast<uint16_t*>(&h);
+    }
+    static __device__ __forceinline__ void copy(T* d, const T* s) { *d = *s; }
+};
+template <>
+struct Storage<kPBF16> {
+    using T = uint16_t;
+    using Acc = float;
+    static __device__ __forceinline__ Acc load(const T* p) { return __uint_as_float((uint32_t)(*p) << 16); }
+    static __device__ __forceinline__ void store(T* p, Acc v)
+    {
+        uint32_t u = __float_as_uint(v);
+        *p = ((u & 0x7fffffffu) > 0x7f800000u) ? (uint16_t)((u >> 16) | 0x40u)
+                                               : (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    static __device__ __forceinline__ void copy(T* d, const T* s) { *d = *s; }
+};
+
+struct PolyParams {
+    const void* points;     // [B, P, D]
+    const void* distances;  // [B, Q] or null (lengths only)
+    const void* point_counts;  // null = all P valid
+    const void* dist_counts;   // null = all Q valid
+    void* out_points;       // [B, Q, D] or null
+    void* out_lengths;      // [B] or null
+    void* scratch;          // [B, P] accumulation-type elements, used when P does not fit LDS
+    long long batch;
+    int P, Q, D;
+    int counts_i64, relative, use_scratch;
+};
+
+__device__ __forceinline__ long long load_count(const void* p, long long i, int is64)
+{
+    return is64 ? static_cast<const long long*>(p)[i] : (long long)static_cast<const int*>(p)[i];
+}
+
+template <int TY>
+__global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
+{
+    using S = Storage<TY>;
+    using T = typename S::T;
+    using Acc = typename S::Acc;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ Acc s_part[kThreads];
+
+    const long long b = blockIdx.x;
+    const int t = threadIdx.x;
+    int n = p.P, q = p.Q;
+    if (p.point_counts) n = (int)max(0ll, min((long long)p.P, load_count(p.point_counts, b, p.counts_i64)));
+    if (p.dist_counts) q = (int)max(0ll, min((long long)p.Q, load_count(p.dist_counts, b, p.counts_i64)));
+    const T* pts = static_cast<const T*>(p.points) + (size_t)b * p.P * p.D;
+    T* out = p.out_points ? static_cast<T*>(p.out_points) + (size_t)b * p.Q * p.D : nullptr;
+    const Acc nan = std::numeric_limits<Acc>::quiet_NaN();
+
+    if (n == 0) {  // undefined polyline: NaN everywhere (polyline_kernels.cuh:216-225)
+        if (out)
+            for (int i = t; i < q * p.D; i += kThreads) S::store(out + i, nan);
+        if (p.out_lengths && t == 0) S::store(static_cast<T*>(p.out_lengths) + b, nan);
+        return;
+    }
+
+    Acc* accum = p.use_scratch ? static_cast<Acc*>(p.scratch) + (size_t)b * p.P : reinterpret_cast<Acc*>(lds_raw);
+
+    // ---- segment lengths, chunked: thread t owns segments [lo, hi), writes the chunk-local inclusive prefix
+    const int n_seg = n - 1;
+    const int per = (n_seg + kThreads - 1) / kThreads;
+    const int lo = min(t * per, n_seg), hi = min(lo + per, n_seg);
+    Acc run = 0;
+    for (int s = lo; s < hi; ++s) {
+        Acc sq = 0;
+        for (int d = 0; d < p.D; ++d) {
+            const Acc diff = S::load(pts + (size_t)s * p.D + d) - S::load(pts + (size_t)(s + 1) * p.D + d);
+            sq += diff * diff;
+        }
+        run += sqrt(sq);
+        accum[s + 1] = run;
+    }
+    if (t == 0) accum[0] = 0;
+    s_part[t] = run;
+    __syncthreads();
+    // ---- exclusive scan of the 256 chunk totals by wave 0 (4 per lane + 64-lane shuffle scan)
+    if (t < 64) {
+        Acc v0 = s_part[4 * t], v1 = s_part[4 * t + 1], v2 = s_part[4 * t + 2], v3 = s_part[4 * t + 3];
+        const Acc lane_total = v0 + v1 + v2 + v3;
+        Acc incl = lane_total;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const Acc up = __shfl_up(incl, off, 64);
+            if (t >= off) incl += up;
+        }
+        const Acc excl = incl - lane_total;
+        s_part[4 * t] = excl;
+        s_part[4 * t + 1] = excl + v0;
+        s_part[4 * t + 2] = excl + v0 + v1;
+        s_part[4 * t + 3] = excl + v0 + v1 + v2;
+    }
+    __syncthreads();
+    const Acc base = s_part[t];
+    if (base != 0)
+        for (int s = lo; s < hi; ++s) accum[s + 1] += base;
+    if (p.use_scratch) __threadfence_block();
+    __syncthreads();
+
+    const Acc total = accum[n - 1];
+    if (p.out_lengths && t == 0) S::store(static_cast<T*>(p.out_lengths) + b, total);
+    if (!out) return;
+
+    // ---- queries
+    const T* dist = static_cast<const T*>(p.distances) + (size_t)b * p.Q;
+    const Acc eps = std::numeric_limits<Acc>::epsilon();
+    for (int i = t; i < q; i += kThreads) {
+        Acc d = S::load(dist + i);
+        if (p.relative) d *= total;
+        T* res = out + (size_t)i * p.D;
+        // last index whose accumulated distance is <= d (polyline_common.cuh:89-116)
+        int idx;
+        if (accum[0] > d) {
+            idx = -1;
+        } else if (accum[n - 1] < d) {
+            idx = n - 1;
+        } else {
+            int mn = 0, mx = n - 1;
+            while (mx - mn > 1) {
+                const int c = (mx + mn) >> 1;
+                const Acc v = accum[c];
+                if (v < d) mn = c;
+                else if (v > d) mx = c;
+                else mn = mx = c;
+            }
+            idx = mn;
+        }
+        if (idx >= 0 && idx < n - 1) {
+            const Acc d0 = accum[idx], d1 = accum[idx + 1], len = d1 - d0;
+            const T* a = pts + (size_t)idx * p.D;
+            const T* c = a + p.D;
+            if (len >= eps) {
+                const Acc w1 = (d - d0) / len, w0 = (d1 - d) / len;
+                for (int k = 0; k < p.D; ++k) S::store(res + k, S::load(a + k) * w0 + S::load(c + k) * w1);
+            } else {
+                for (int k = 0; k < p.D; ++k) S::copy(res + k, a + k);
+            }
+        } else if (idx == -1) {
+            for (int k = 0; k < p.D; ++k) S::copy(res + k, pts + k);
+        } else {
+            for (int k = 0; k < p.D; ++k) S::copy(res + k, pts + (size_t)(n - 1) * p.D + k);
+        }
+    }
+}
+
+inline size_t acc_size(int ty) { return ty == kPF64 ? 8 : 4; }
+
+}  // namespace
+
+extern "C" {
+
+size_t accv_polyline_scratch_bytes(long long batch, int max_points, int dtype)
+{
+    if (batch <= 0 || max_points <= 0) return 0;
+    const size_t need = (size_t)max_points * acc_size(dtype);
+    return need <= (size_t)kLdsBudgetBytes ? 0 : need * (size_t)batch;
+}
+
+int accv_polyline_sample(const void* points, const void* distances, const void* point_counts, const void* dist_counts,
+                         void* out_points, void* out_lengths, long long batch, int max_points, int max_distances,
+                         int num_dims, int dtype, int counts_i64, int relative, void* scratch, size_t scratch_bytes,
+                         void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (batch < 0 || max_points < 0 || max_distances < 0 || num_dims < 0)
+        return accv::fail(ACCV_EINVAL, "polyline: negative extent");
+    if (dtype < kPF32 || dtype > kPBF16) return accv::fail(ACCV_EINVAL, "polyline: unsupported dtype code %d", dtype);
+    if (batch == 0) return ACCV_OK;
+    if (!out_points && !out_lengths) return ACCV_OK;
+    if (out_points && (max_distances == 0 || num_dims == 0) && !out_lengths) return ACCV_OK;
+    if (max_points > 0 && num_dims > 0 && !points) return accv::fail(ACCV_EINVAL, "polyline: null points");
+    if (out_points && max_distances > 0 && !distances) return accv::fail(ACCV_EINVAL, "polyline: null distances");
+    PolyParams p{};
+    p.points = points;
+    p.distances = distances;
+    p.point_counts = point_counts;
+    p.dist_counts = dist_counts;
+    p.out_points = (max_distances > 0 && num_dims > 0) ? out_points : nullptr;
+    p.out_lengths = out_lengths;
+    p.batch = batch;
+    p.P = max_points;
+    p.Q = max_distances;
+    p.D = num_dims;
+    p.counts_i64 = counts_i64;
+    p.relative = relative;
+    const size_t need = accv_polyline_scratch_bytes(batch, max_points, dtype);
+    size_t lds = (size_t)std::max(1, max_points) * acc_size(dtype);
+    if (need > 0) {
+        if (!scratch || scratch_bytes < need)
+            return accv::fail(ACCV_EWORKSPACE, "polyline: %d points per polyline need %zu bytes of scratch", max_points, need);
+        p.scratch = scratch;
+        p.use_scratch = 1;
+        lds = 16;
+    }
+    if (!p.out_points && !p.out_lengths) return ACCV_OK;
+    const dim3 grid((unsigned)batch), block(kThreads);
+    switch (dtype) {
+        case kPF32: hipLaunchKernelGGL((polyline_kernel<kPF32>), grid, block, lds, stream, p); break;
+        case kPF64: hipLaunchKernelGGL((polyline_kernel<kPF64>), grid, block, lds, stream, p); break;
+        case kPF16: hipLaunchKernelGGL((polyline_kernel<kPF16>), grid, block, lds, stream, p); break;
+        default: hipLaunchKernelGGL((polyline_kernel<kPBF16>), grid, block, lds, stream, p); break;
+    }
+    return accv::check_launch("polyline");
+}
+}

@@ -171,6 +171,20 @@ int accv_mtc_coalesce(const void* items, long long n_items, void* packed, int sc
 /* hipMemcpyAsync wrapper: kind 1 = H2D, 2 = D2H, 3 = D2D, anything else = default. */
 int accv_memcpy_async(void* dst, const void* src, size_t bytes, int kind, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ lane_helpers
+ * Batched polyline arc-length interpolation / lengths.  Replaces the four entry points of
+ * packages/lane_helpers/ext_impl/polyline/src/polyline.cpp:101-398 (polyline_interpolation, _polyline_lengths and
+ * their _var_size_batch forms; kernels include/polyline_kernels.cuh:390-455, semantics include/polyline_common.cuh
+ * :58-163).  points [batch, max_points, dims], distances [batch, max_distances] (same dtype), optional per-polyline
+ * counts (int32/int64; NULL = all valid).  out_points [batch, max_distances, dims] and/or out_lengths [batch] may be
+ * NULL.  dtype: 0 f32, 1 f64, 2 f16, 3 bf16 (accumulation fp32, fp64 for f64).  relative != 0: distances are
+ * fractions of the total length.  Polylines too long for LDS need accv_polyline_scratch_bytes() of device scratch. */
+size_t accv_polyline_scratch_bytes(long long batch, int max_points, int dtype);
+int accv_polyline_sample(const void* points, const void* distances, const void* point_counts, const void* dist_counts,
+                         void* out_points, void* out_lengths, long long batch, int max_points, int max_distances,
+                         int num_dims, int dtype, int counts_i64, int relative, void* scratch, size_t scratch_bytes,
+                         void* stream);
+
 /* Streaming fill used by bench.py as the measured write-bandwidth ceiling (not part of the reference API). */
 int accv_fill_f32(float* dst, size_t count, float value, void* stream);
 

@@ -1,0 +1,151 @@
+"""lane_helpers polyline ops: oracle pinned to golden vectors of the reference's own test oracle; CPU product path and
+(marked gpu) the HIP kernel against the same vectors.  Tolerance 1e-5 abs as in the reference
+(packages/lane_helpers/tests/polyline_test_utils.py:100,115); the golden values were computed in fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lane as oracle
+
+Z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lane_polyline.npz"), allow_pickle=False)
+FIXED = ["rect", "batched", "deg", "one"] + [f"rand{k}" for k in range(12)]
+RAGGED = [f"rag{k}" for k in range(6)]
+ATOL = 1e-5
+
+
+def _poly():
+    from accvlab.lane_helpers import polyline
+    return polyline
+
+
+@pytest.mark.parametrize("name", FIXED)
+def test_oracle_matches_reference_vectors_fixed(name):
+    p, d, e = Z[f"{name}_points"], Z[f"{name}_dist"], Z[f"{name}_expected"]
+    for b in range(p.shape[0]):
+        got = oracle.sample(p[b], d[b])
+        assert np.allclose(got, e[b], atol=ATOL, rtol=0)
+        if f"{name}_length" in Z.files:
+            assert abs(oracle.length(p[b]) - Z[f"{name}_length"][b]) <= 1e-4
+
+
+@pytest.mark.parametrize("name", RAGGED)
+def test_oracle_matches_reference_vectors_ragged(name):
+    p, d, e = Z[f"{name}_points"], Z[f"{name}_dist"], Z[f"{name}_expected"]
+    ps, qs, ln = Z[f"{name}_psizes"], Z[f"{name}_qsizes"], Z[f"{name}_length"]
+    for b in range(p.shape[0]):
+        got = oracle.sample(p[b, :ps[b]], d[b, :qs[b]])
+        assert np.allclose(got, e[b, :qs[b]], atol=ATOL, rtol=0, equal_nan=True)
+        assert np.isnan(ln[b]) == (ps[b] == 0)
+        if ps[b] > 0:
+            assert abs(oracle.length(p[b, :ps[b]]) - ln[b]) <= 1e-4
+
+
+def _run_fixed(dev, name, relative):
+    poly = _poly()
+    p, d, e = torch.from_numpy(Z[f"{name}_points"]), torch.from_numpy(Z[f"{name}_dist"]), Z[f"{name}_expected"]
+    din = d
+    if relative:
+        tot = torch.linalg.vector_norm(p[:, 1:] - p[:, :-1], dim=2).sum(1) if p.shape[1] > 1 else torch.zeros(p.shape[0])
+        if float(tot.min()) <= 0:
+            return
+        din = d / tot[:, None]
+    got = poly.interpolate(p.to(dev), din.to(dev), relative=relative)
+    assert got.shape == e.shape and got.dtype == p.dtype and got.device.type == torch.device(dev).type
+    assert np.allclose(got.cpu().numpy(), e, atol=2e-5 if relative else ATOL, rtol=0)
+    if f"{name}_length" in Z.files:
+        ln = poly.lengths(p.to(dev))
+        assert np.allclose(ln.cpu().numpy(), Z[f"{name}_length"], atol=1e-4, rtol=0)
+
+
+def _run_ragged(dev, name, idt):
+    from accvlab.batching_helpers import RaggedBatch
+
+    poly = _poly()
+    p, d = torch.from_numpy(Z[f"{name}_points"]), torch.from_numpy(Z[f"{name}_dist"])
+    ps, qs = torch.from_numpy(Z[f"{name}_psizes"]).to(idt), torch.from_numpy(Z[f"{name}_qsizes"]).to(idt)
+    prb = RaggedBatch(p.to(dev), sample_sizes=ps.to(dev))
+    drb = RaggedBatch(d.to(dev), sample_sizes=qs.to(dev))
+    res = poly.interpolate_var_size_batch(prb, drb)
+    assert isinstance(res, RaggedBatch) and torch.equal(res.sample_sizes.cpu(), qs)
+    e = Z[f"{name}_expected"]
+    for b in range(p.shape[0]):
+        n = int(qs[b])
+        assert np.allclose(res.tensor[b, :n].cpu().numpy(), e[b, :n], atol=ATOL, rtol=0, equal_nan=True), (name, b)
+    ln = poly.lengths_var_size_batch(prb).cpu().numpy()
+    assert np.allclose(ln, Z[f"{name}_length"], atol=1e-4, rtol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("relative", [False, True])
+@pytest.mark.parametrize("name", FIXED)
+def test_cpu_fixed(name, relative):
+    _run_fixed("cpu", name, relative)
+
+
+@pytest.mark.parametrize("name", RAGGED)
+def test_cpu_ragged(name):
+    _run_ragged("cpu", name, torch.int64)
+
+
+def test_cpu_edge_cases_and_validation():
+    poly = _poly()
+    empty = poly.interpolate(torch.empty((2, 0, 3)), torch.tensor([[0.0, 1.0], [-1.0, 2.0]]))
+    assert empty.shape == (2, 2, 3) and bool(torch.isnan(empty).all())
+    assert poly.interpolate(torch.empty((2, 0, 3)), torch.empty((2, 0))).shape == (2, 0, 3)
+    assert bool(torch.isnan(poly.lengths(torch.empty((2, 0, 3)))).all())
+    assert poly.lengths(torch.ones((2, 1, 3))).tolist() == [0.0, 0.0]
+    nc = torch.tensor([[[0.0, 1.0, 1.0, 0.0], [0.0, 0.0, 2.0, 2.0]]]).transpose(1, 2)   # non-contiguous input
+    out = poly.interpolate(nc, torch.tensor([[0.5, 2.0]]))
+    assert np.allclose(out.numpy(), [[[0.5, 0.0], [1.0, 1.0]]], atol=1e-6)
+    with pytest.raises(RuntimeError):
+        poly.interpolate(torch.zeros(2, 3), torch.zeros(2, 1))
+    with pytest.raises(RuntimeError):
+        poly.interpolate(torch.zeros(2, 3, 2), torch.zeros(3, 1))
+    with pytest.raises(RuntimeError):
+        poly.interpolate(torch.zeros(2, 3, 2), torch.zeros(2, 1, dtype=torch.float64))
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("relative", [False, True])
+@pytest.mark.parametrize("name", FIXED)
+def test_gpu_fixed(name, relative):
+    _run_fixed("cuda:0", name, relative)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idt", [torch.int64, torch.int32])
+@pytest.mark.parametrize("name", RAGGED)
+def test_gpu_ragged(name, idt):
+    _run_ragged("cuda:0", name, idt)
+
+
+@pytest.mark.gpu
+def test_gpu_dtypes_long_polylines_and_edge_cases():
+    poly = _poly()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    # long polylines: LDS path (8k points) and the global-scratch path (20k points > 48 KB of fp32)
+    for npnt in (8192, 20000):
+        p = torch.rand((3, npnt, 2), generator=g, dtype=torch.float64)
+        tot = torch.linalg.vector_norm(p[:, 1:] - p[:, :-1], dim=2).sum(1)
+        d = torch.rand((3, 300), generator=g, dtype=torch.float64) * tot[:, None]
+        ref = np.stack([oracle.sample(p[b].numpy(), d[b].numpy()) for b in range(3)])
+        got64 = poly.interpolate(p.to(dev), d.to(dev))
+        assert np.allclose(got64.cpu().numpy(), ref, atol=1e-9, rtol=0)
+        got32 = poly.interpolate(p.float().to(dev), d.float().to(dev))
+        assert np.abs(got32.cpu().numpy() - ref).max() < 5e-3      # fp32 accumulation over ~1e4 segments
+        assert np.allclose(poly.lengths(p.to(dev)).cpu().numpy(), tot.numpy(), rtol=1e-12)
+    p = torch.rand((4, 40, 3), generator=g)
+    tot = torch.linalg.vector_norm(p[:, 1:] - p[:, :-1], dim=2).sum(1)
+    d = torch.rand((4, 25), generator=g) * tot[:, None]
+    ref = np.stack([oracle.sample(p[b].numpy(), d[b].numpy()) for b in range(4)])
+    for dt, tol in ((torch.float16, 2e-2), (torch.bfloat16, 1e-1)):
+        got = poly.interpolate(p.to(dev, dt), d.to(dev, dt))
+        assert got.dtype == dt and np.abs(got.float().cpu().numpy() - ref).max() < tol
+    empty = poly.interpolate(torch.empty((2, 0, 3), device=dev), torch.tensor([[0.0, 1.0], [-1.0, 2.0]], device=dev))
+    assert empty.shape == (2, 2, 3) and bool(torch.isnan(empty).all())
+    assert poly.interpolate(torch.empty((2, 0, 3), device=dev), torch.empty((2, 0), device=dev)).shape == (2, 0, 3)
+    assert bool(torch.isnan(poly.lengths(torch.empty((2, 0, 3), device=dev))).all())
+    assert poly.lengths(torch.ones((2, 1, 3), device=dev)).tolist() == [0.0, 0.0]
