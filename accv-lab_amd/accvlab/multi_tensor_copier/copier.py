@@ -251,8 +251,14 @@ def _run(job: _Job) -> None:
             side = _side_stream(sdev)
             with torch.cuda.device(sdev):
                 side.wait_event(job.source_events[sdev.index])
+                small = [i for i in idxs if job.pack and leaves[i].is_contiguous()
+                         and 0 < leaves[i].numel() * leaves[i].element_size() <= PACK_MAX_BYTES_PER_TENSOR]
+                packed_ok = False
+                if len(small) >= 2:
+                    packed_ok = _coalesced_d2h(job, lib, small, sdev, side)
+                rest = [i for i in idxs if not (packed_ok and i in set(small))]
                 with torch.cuda.stream(side):
-                    for i in idxs:
+                    for i in rest:
                         t = leaves[i]
                         out = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=job.pinned)
                         out.copy_(t, non_blocking=job.pinned)
@@ -260,6 +266,50 @@ def _run(job: _Job) -> None:
                 done = torch.cuda.Event()
                 done.record(side)
                 job.events.append(done)
+
+
+def _coalesced_d2h(job: _Job, lib, small: List[int], sdev: torch.device, side) -> bool:
+    """Many small device tensors -> ONE device gather kernel (accv_mtc_coalesce) -> ONE D2H transfer per chunk -> host
+    views (the reference copies each tensor separately, multi_tensor_copier.cpp:790-800)."""
+    leaves = job.leaves
+    m = len(small)
+    nbytes = np.fromiter((leaves[i].numel() * leaves[i].element_size() for i in small), np.int64, m)
+    esize = np.fromiter((leaves[i].element_size() for i in small), np.int32, m)
+    off = np.empty(m, dtype=np.int64)
+    chk = np.empty(m, dtype=np.int64)
+    csz = np.empty(m, dtype=np.int64)
+    nck = ctypes.c_longlong(0)
+    _nat.check(lib.accv_mtc_plan(m, nbytes.ctypes.data, esize.ctypes.data, np.ones(m, dtype=np.uint8).ctypes.data,
+                                 job.min_align, job.max_chunk, off.ctypes.data, chk.ctypes.data, csz.ctypes.data,
+                                 ctypes.addressof(nck)), "mtc_plan")
+    n_chunks = int(nck.value)
+    if n_chunks == 0:
+        return False
+    ptrs = np.fromiter((leaves[i].data_ptr() for i in small), np.uint64, m)
+    with torch.cuda.stream(side):
+        for c in range(n_chunks):
+            sel = np.nonzero(chk == c)[0]
+            size = int(csz[c])
+            table = np.empty((len(sel), 3), dtype=np.int64)      # {src pointer, offset in packed, nbytes}
+            table[:, 0] = ptrs[sel].view(np.int64)
+            table[:, 1] = off[sel]
+            table[:, 2] = nbytes[sel]
+            items = torch.from_numpy(table).to(sdev, non_blocking=False)
+            packed = torch.empty(size + 16, dtype=torch.uint8, device=sdev)
+            _nat.check(lib.accv_mtc_coalesce(items.data_ptr(), len(sel), packed.data_ptr(), 0, side.cuda_stream),
+                       "mtc_coalesce")
+            host = torch.empty(size + 16, dtype=torch.uint8, device="cpu", pin_memory=job.pinned)
+            host.copy_(packed, non_blocking=job.pinned)
+            job.keep.append((items, packed))
+            typed = {}
+            for k in sel:
+                t = leaves[small[k]]
+                tv = typed.get(t.dtype)
+                if tv is None:
+                    tv = host[: (size + 15) // 16 * 16].view(t.dtype)
+                    typed[t.dtype] = tv
+                job.outs[small[k]] = torch.as_strided(tv, t.shape, t.stride(), int(off[k]) // t.element_size())
+    return True
 
 
 class AsyncCopyHandle:

@@ -45,6 +45,7 @@ struct SplatParams {
     float factor, k;
     int counts_i64;
     int plane_minor;      // tile order: 0 = plane-major (tiles of a plane adjacent), 1 = planes interleaved
+    int grid3d;           // tile index comes from a 3-D grid instead of a linear block index
     long long n_planes;
 };
 
@@ -87,26 +88,33 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long tile = (long long)blockIdx.x * kWavesPerGroup + wave;
-    if (tile >= p.n_tiles) return;  // whole wave exits; waves never synchronise with each other
-
     int tx, ty;
     long long plane;
-    if (p.plane_minor) {
-        // groups of kWavesPerGroup column tiles stay together; planes vary fastest across workgroups
-        const long long grp = tile / kWavesPerGroup;
-        const int w = (int)(tile - grp * kWavesPerGroup);
-        plane = grp % p.n_planes;
-        const long long rest = grp / p.n_planes;
-        const int gx = (p.tiles_x + kWavesPerGroup - 1) / kWavesPerGroup;
-        tx = (int)(rest % gx) * kWavesPerGroup + w;
-        ty = (int)(rest / gx);
-        if (tx >= p.tiles_x || ty >= p.tiles_y) return;
+    if (p.grid3d) {
+        // 3-D grid (x = group of WPG column tiles, y = row tile, z = plane): no divisions in the prologue
+        tx = blockIdx.x * kWavesPerGroup + wave;
+        ty = blockIdx.y;
+        plane = blockIdx.z;
+        if (tx >= p.tiles_x) return;
     } else {
-        tx = (int)(tile % p.tiles_x);
-        const long long t2 = tile / p.tiles_x;
-        ty = (int)(t2 % p.tiles_y);
-        plane = t2 / p.tiles_y;
+        const long long tile = (long long)blockIdx.x * kWavesPerGroup + wave;
+        if (tile >= p.n_tiles) return;  // whole wave exits; waves never synchronise with each other
+        if (p.plane_minor) {
+            // groups of kWavesPerGroup column tiles stay together; planes vary fastest across workgroups
+            const long long grp = tile / kWavesPerGroup;
+            const int w = (int)(tile - grp * kWavesPerGroup);
+            plane = grp % p.n_planes;
+            const long long rest = grp / p.n_planes;
+            const int gx = (p.tiles_x + kWavesPerGroup - 1) / kWavesPerGroup;
+            tx = (int)(rest % gx) * kWavesPerGroup + w;
+            ty = (int)(rest / gx);
+            if (tx >= p.tiles_x || ty >= p.tiles_y) return;
+        } else {
+            tx = (int)(tile % p.tiles_x);
+            const long long t2 = tile / p.tiles_x;
+            ty = (int)(t2 % p.tiles_y);
+            plane = t2 / p.tiles_y;
+        }
     }
 
     const int tx0 = tx * TW, ty0 = ty * TH;
@@ -252,6 +260,180 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
     }
 }
 
+// ---------------------------------------------------------------- v2: one store per wave ("row-pair waves")
+// Store-pattern microbenchmarks (profiles/r01_fill_patterns3_*.log) show that waves issuing ONE 16-byte-per-lane
+// store reach 6.5-7.3 TB/s while any wave with >= 2 stores plateaus ~15-20 % lower.  So here a WORKGROUP of NW waves
+// owns a 128 x (2*NW) tile: wave 0 culls (ballot compaction, as above), all threads build LDS tables
+//   s_ex[hit][128 columns] = exp2(-dx^2 c)      (NaN outside the clipped columns)
+//   s_ey[row][hit]         = k exp2(-dy^2 c)    (NaN outside the clipped rows)
+// and each wave then owns rows (2w, 2w+1): per hit one ds_read_b128 of column factors, one broadcast row factor,
+// 4 multiplies + 4 max — and exactly ONE write-through store at the end.
+template <int NW, bool CLEAR, int SM>
+__global__ __launch_bounds__(NW * 64) void splat_rows_kernel(const SplatParams p)
+{
+    constexpr int TW = 128, TH = 2 * NW;
+    __shared__ HitX s_hx[kCand];
+    __shared__ HitY s_hy[kCand];
+    __shared__ __attribute__((aligned(16))) float s_ex[kCand][TW];
+    __shared__ __attribute__((aligned(16))) float s_ey[TH][kCand];
+    __shared__ int s_nh;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 3-D grid (x = column tile, y = row tile, z = plane): no divisions in the per-wave prologue
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    const unsigned plane = blockIdx.z;
+    const int tx0 = tx * TW, ty0 = ty * TH;
+    const int tx1 = min(tx0 + TW, p.W), ty1 = min(ty0 + TH, p.H);
+
+    unsigned obj_base;
+    int n, cls = -1;
+    const bool flat = p.obj_list != nullptr;
+    if (flat) {
+        const int o0 = p.plane_off[plane];
+        obj_base = (unsigned)o0;
+        n = p.plane_off[plane + 1] - o0;
+    } else {
+        unsigned s = plane;
+        if (p.n_classes > 0) {
+            s = plane / (unsigned)p.n_classes;
+            cls = (int)(plane - s * (unsigned)p.n_classes);
+        }
+        const long long cnt = p.counts_i64 ? ((const long long*)p.counts)[s] : (long long)((const int*)p.counts)[s];
+        n = (int)max(0ll, min(cnt, (long long)p.n_max));
+        obj_base = s * (unsigned)p.n_max;
+    }
+
+    const int row = ty0 + 2 * wave + (lane >> 5);
+    const int colq = (lane & 31);  // float4 column group inside the tile
+    const int col0 = tx0 + colq * 4;
+    const float nanv = __builtin_nanf("");
+    float acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = CLEAR ? 0.0f : nanv;
+    int total_hits = 0;
+
+    for (int base = 0; base < n; base += kCand) {
+        if (wave == 0) {  // cull: one candidate per lane of wave 0
+            const int ci = base + lane;
+            bool hit = false;
+            int x = 0, y = 0, r = 0;
+            if (ci < n) {
+                const unsigned o = flat ? (unsigned)p.obj_list[obj_base + ci] : obj_base + ci;
+                const int2 cxy = reinterpret_cast<const int2*>(p.centers)[o];
+                x = cxy.x;
+                y = cxy.y;
+                r = p.radii[o];
+                hit = true;
+                if (cls >= 0) hit = p.labels[o] == cls;
+            }
+            const long long x0 = (long long)x - min(x, r), x1 = (long long)x + min((long long)p.W - x, (long long)r + 1);
+            const long long y0 = (long long)y - min(y, r), y1 = (long long)y + min((long long)p.H - y, (long long)r + 1);
+            hit = hit && x1 > x0 && y1 > y0 && x0 < tx1 && x1 > tx0 && y0 < ty1 && y1 > ty0;
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int pos = __popcll(m & ((1ull << lane) - 1ull));
+                const float sigma = (float)(2 * r + 1) / p.factor;
+                const float c2 = kLog2e / (2.0f * sigma * sigma);
+                s_hx[pos] = HitX{x, c2, (int)x0, (int)x1};
+                s_hy[pos] = HitY{y, c2, (int)y0, (int)y1};
+            }
+            if (lane == 0) s_nh = __popcll(m);
+        }
+        __syncthreads();
+        const int nh = s_nh;
+        if (nh > 0) {
+            const int nh4 = (nh + 3) & ~3;
+            // column factors: consecutive threads -> consecutive columns of one hit
+            for (int i = tid; i < nh * TW; i += NW * 64) {
+                const int h = i / TW, c = i % TW;
+                const HitX hx = s_hx[h];
+                const int col = tx0 + c;
+                const float d = (float)(col - hx.x);
+                const float e = raw_exp2(-(d * d) * hx.c2);
+                s_ex[h][c] = (col >= hx.x0 && col < hx.x1) ? e : nanv;
+            }
+            // row factors, [row][hit] so that a wave fetches four hits of its row with one ds_read_b128
+            for (int i = tid; i < TH * nh4; i += NW * 64) {
+                const int rr = i / nh4, h = i % nh4;
+                float v = nanv;
+                if (h < nh) {
+                    const HitY hy = s_hy[h];
+                    const int rw = ty0 + rr;
+                    const float d = (float)(rw - hy.y);
+                    if (rw >= hy.y0 && rw < hy.y1) v = p.k * raw_exp2(-(d * d) * hy.c2);
+                }
+                s_ey[rr][h] = v;
+            }
+            __syncthreads();
+            const int myrow = 2 * wave + (lane >> 5);
+            for (int h4 = 0; h4 < nh4; h4 += 4) {
+                const float4 ey4 = *reinterpret_cast<const float4*>(&s_ey[myrow][h4]);
+                const float ey[4] = {ey4.x, ey4.y, ey4.z, ey4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (h4 + j < nh) {
+                        const float4 ex4 = *reinterpret_cast<const float4*>(&s_ex[h4 + j][colq * 4]);
+                        acc[0] = fmaxf(acc[0], ex4.x * ey[j]);
+                        acc[1] = fmaxf(acc[1], ex4.y * ey[j]);
+                        acc[2] = fmaxf(acc[2], ex4.z * ey[j]);
+                        acc[3] = fmaxf(acc[3], ex4.w * ey[j]);
+                    }
+                }
+            }
+            total_hits += nh;
+        }
+        __syncthreads();  // tables and s_nh are reused by the next round
+    }
+
+    if (!CLEAR && total_hits == 0) return;
+    if (row >= p.H || col0 >= p.W) return;
+    float* plane_ptr = p.hm + (size_t)plane * (size_t)p.H * (size_t)p.W;
+    vfloat4* dst = reinterpret_cast<vfloat4*>(plane_ptr + (size_t)row * p.W + col0);
+    vfloat4 out;
+    if constexpr (!CLEAR) {
+        const vfloat4 old = *dst;
+        out = vfloat4{fmaxf(old.x, acc[0]), fmaxf(old.y, acc[1]), fmaxf(old.z, acc[2]), fmaxf(old.w, acc[3])};
+    } else {
+        out = vfloat4{acc[0], acc[1], acc[2], acc[3]};
+    }
+    if constexpr (SM >= 2) {
+        constexpr int aux = SM == 2 ? 16 : SM == 3 ? 17 : SM == 4 ? 18 : SM == 5 ? 19 : SM == 6 ? 0 : 2;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(out, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, aux);
+    } else if constexpr (SM == 1) {
+        __builtin_nontemporal_store(out, dst);
+    } else {
+        *dst = out;
+    }
+}
+
+template <int NW>
+int launch_splat_rows(SplatParams p, long long planes, bool clear, int sm, hipStream_t stream)
+{
+    p.tiles_x = (p.W + 127) / 128;
+    p.tiles_y = (p.H + 2 * NW - 1) / (2 * NW);
+    p.n_tiles = planes * p.tiles_x * p.tiles_y;
+    if (p.n_tiles == 0) return ACCV_OK;
+    const dim3 grid((unsigned)p.tiles_x, (unsigned)p.tiles_y, (unsigned)planes), block(NW * 64);
+#define ACCV_LAUNCH_ROWS(SMV)                                                                            \
+    do {                                                                                                 \
+        if (clear)                                                                                       \
+            hipLaunchKernelGGL((splat_rows_kernel<NW, true, SMV>), grid, block, 0, stream, p);           \
+        else                                                                                             \
+            hipLaunchKernelGGL((splat_rows_kernel<NW, false, SMV>), grid, block, 0, stream, p);          \
+    } while (0)
+    switch (sm) {
+        case 2: ACCV_LAUNCH_ROWS(2); break;
+        case 4: ACCV_LAUNCH_ROWS(4); break;
+        case 6: ACCV_LAUNCH_ROWS(6); break;
+        default: ACCV_LAUNCH_ROWS(0); break;
+    }
+#undef ACCV_LAUNCH_ROWS
+    return accv::check_launch("draw_heatmap row-pair splat kernel");
+}
+
 // ---------------------------------------------------------------- target-prep front end
 // centres/boxes (float, source-image pixels) -> integer centre + radius at an output stride; one fused kernel for
 // the ~8 element-wise torch ops of the reference helper (packages/draw_heatmap/tests/_test_helpers.py:20-28):
@@ -346,7 +528,9 @@ int launch_splat(SplatParams p, long long planes, bool clear, int nt, hipStream_
     const long long groups = (p.n_tiles + kWavesPerGroup - 1) / kWavesPerGroup;
     if (groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap: %lld tiles exceed the grid limit", p.n_tiles);
     if (groups == 0) return ACCV_OK;
-    const dim3 grid((unsigned)groups), block(kWavesPerGroup * 64);
+    dim3 grid((unsigned)groups), block(kWavesPerGroup * 64);
+    p.grid3d = (!p.plane_minor && planes <= 65535 && p.tiles_y <= 65535 && accv::tune_get("hm_grid3d", 1)) ? 1 : 0;
+    if (p.grid3d) grid = dim3((unsigned)((p.tiles_x + kWavesPerGroup - 1) / kWavesPerGroup), (unsigned)p.tiles_y, (unsigned)planes);
     const int sm = nt;  // store mode: 0 plain, 1 nontemporal, 2 sc1, 3 sc0+sc1, 4 sc1+nt
 #define ACCV_LAUNCH_SM(SMV)                                                                                        \
     do {                                                                                                           \
@@ -385,6 +569,16 @@ int dispatch_splat(const SplatParams& p, long long planes, bool clear, hipStream
     if (nt < 0) nt = (total_bytes > ((size_t)128 << 20) && plane_fits_rsrc) ? 4 : 0;
     if (nt >= 2 && !plane_fits_rsrc) nt = 0;
     const int rows = accv::tune_get("hm_rows", 8);
+    const int kernel = accv::tune_get("hm_kernel", 1);
+    // the row-pair kernel addresses objects/planes with 32-bit math and a 3-D grid
+    const bool fits32 = planes <= 65535 && (long long)planes * std::max(p.n_max, 1) < (1ll << 31) &&
+                        (p.H + 7) / 8 <= 65535;
+    if (vec4 && kernel == 2 && fits32) {
+        const int nw = accv::tune_get("hm_nw", 16);
+        if (nw == 8) return launch_splat_rows<8>(p, planes, clear, nt, stream);
+        if (nw == 4) return launch_splat_rows<4>(p, planes, clear, nt, stream);
+        return launch_splat_rows<16>(p, planes, clear, nt, stream);
+    }
     const int wpg = accv::tune_get("hm_wpg", kWavesPerGroup);
     if (vec4) {
         if (rows == 16 && accv::tune_get("hm_lpr", 32) != 64) return launch_splat<4, 16>(p, planes, clear, nt, stream);

@@ -150,6 +150,7 @@ def main():
 
     if rank != 0:
         if dist is not None:
+            dist.barrier()          # wait for rank 0's secondary measurements, then leave together
             dist.destroy_process_group()
         return
 
@@ -185,8 +186,9 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(centers_l, radii_l, B)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

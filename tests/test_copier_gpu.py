@@ -167,3 +167,26 @@ def test_exceptions_surface_from_get():
         assert all(torch.equal(a, b.cpu()) for a, b in zip(bad, out))
     except RuntimeError:
         pass
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_many_small_gpu_tensors_to_cpu_are_coalesced(pinned):
+    """small device tensors travel through ONE device gather + ONE transfer; values exact, outputs
+    share one host storage (pinned when requested), large / non-contiguous tensors keep the per-tensor path."""
+    mtc = _mtc()
+    g = torch.Generator().manual_seed(0)
+    data = []
+    for i in range(300):
+        n = int(torch.randint(1, 200, (1,), generator=g))
+        t = torch.rand(n, 3, generator=g) if i % 2 == 0 else torch.randint(0, 99, (n,), generator=g)
+        data.append(t.to(DEV))
+    data.append(torch.rand(400_000, generator=g).to(DEV))                       # > 256 KB: per-tensor path
+    data.append(torch.rand(6, 4, generator=g).to(DEV).t())                      # non-contiguous
+    out = mtc.start_copy({"x": data, "tag": "keep"}, "cpu", use_pinned_staging=pinned).get()
+    assert out["tag"] == "keep"
+    for a, b in zip(data, out["x"]):
+        assert b.device.type == "cpu" and a.shape == b.shape and a.dtype == b.dtype and torch.equal(a.cpu(), b)
+    ptrs = [_storage_ptr(t) for t in out["x"][:300]]
+    assert len(set(ptrs)) == 1
+    if pinned:
+        assert all(t.is_pinned() for t in out["x"][:300])

@@ -22,6 +22,16 @@ def rb(t, sizes):
     return SimpleNamespace(tensor=t, sample_sizes=sizes)
 
 
+@pytest.fixture(autouse=True, params=[1, 2], ids=["wave-tiles", "row-pair-waves"])
+def kernel_variant(request):
+    """every test of this module runs against both splat kernels (tune knob hm_kernel)"""
+    from accvlab import _amd_native as nat
+
+    nat.tune_set("hm_kernel", request.param)
+    yield request.param
+    nat.tune_set("hm_kernel", 1)
+
+
 def _dh():
     from accvlab.draw_heatmap import draw_heatmap, draw_heatmap_batched
     return draw_heatmap, draw_heatmap_batched
