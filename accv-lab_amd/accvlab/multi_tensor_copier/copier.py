@@ -8,14 +8,18 @@ on top of csrc/multi_tensor_copier.cpp:863-883, 922-1065, 1074-1158):
 * host->GPU: contiguous host tensors of 0 < bytes <= 256 KiB are packed (mixed dtypes) into aligned byte chunks of at
   most ``max_packed_chunk_bytes``; each chunk is staged in pinned memory by a native worker pool and moved with ONE
   hipMemcpyAsync; the results are typed views that share one GPU storage per chunk;
-* GPU->host with ``use_pinned_staging`` returns pinned tensors; tensors already on the target device are returned
-  as they are; GPU->GPU and host->host are supported;
+* GPU->host with ``use_pinned_staging`` returns pinned tensors (many small device tensors travel as ONE device-side
+  gather + ONE transfer); tensors already on the target device are returned as they are; GPU->GPU and host->host work;
 * copies are ordered after the work that was enqueued on the caller's current stream at call time; ``get()`` blocks
   until the data is usable from any stream; worker exceptions surface from ``ready()`` / ``get()``.
 
 MI355X-first differences: pinned staging comes from a recycled arena (accv_pinned_*) instead of a fresh pinned
 allocation per call, and the transfers run on a dedicated non-blocking side stream that waits on an event of the
 caller's stream (the reference enqueues on the caller's stream itself) so the DMA overlaps the caller's kernels.
+
+Host overhead: the tree walk, leaf classification, packed-view construction and output rebuild run in the C++ module
+``_mtc_host`` (csrc_host/mtc_host.cpp, pybind11 + ATen) when it has been built; ``_PyLeafSet`` is its pure-python twin
+(same interface) used otherwise.  Both drive the same C-ABI calls of libaccv_hip.so.
 """
 from __future__ import annotations
 
@@ -23,14 +27,20 @@ import ctypes
 import os
 import threading
 from concurrent.futures import Future, ThreadPoolExecutor
-from typing import Any, List, Optional, Tuple
+from typing import Any, List, Optional
 
 import numpy as np
 import torch
 
 from .. import _amd_native as _nat
 
+try:  # C++ host fast path (built by `make -C accv-lab_amd/csrc_host`)
+    from . import _mtc_host as _host
+except ImportError:  # pragma: no cover - exercised when the host extension has not been built
+    _host = None
+
 PACK_MAX_BYTES_PER_TENSOR = 256 * 1024  # multi_tensor_copier.cpp:483
+R_REUSE, R_H2D_PACK, R_H2D_SINGLE, R_D2H_SMALL, R_D2H_OTHER, R_D2D, R_OTHER = range(7)
 
 _pool_lock = threading.Lock()
 _pool: Optional[ThreadPoolExecutor] = None
@@ -55,61 +65,129 @@ def _side_stream(device: torch.device) -> "torch.cuda.Stream":
         return s
 
 
-# ------------------------------------------------------------------------------------------------ tree walk
+# ------------------------------------------------------------------------------------------------ python leaf set
 _T, _L, _D, _X, _P = 0, 1, 2, 3, 4  # tuple, list, dict, tensor leaf, passthrough
 
 
-def _flatten(obj: Any, leaves: List[torch.Tensor]):
-    """Returns a spec; appends tensor leaves (numpy arrays become CPU tensors that share memory when possible)."""
-    if isinstance(obj, torch.Tensor):
-        leaves.append(obj)
-        return (_X, len(leaves) - 1)
-    t = type(obj)
-    if t is list:
-        return (_L, [_flatten(o, leaves) for o in obj])
-    if t is tuple:
-        return (_T, [_flatten(o, leaves) for o in obj])
-    if t is dict:
-        return (_D, list(obj.keys()), [_flatten(o, leaves) for o in obj.values()])
-    if isinstance(obj, np.ndarray):
-        try:
-            ten = torch.from_numpy(obj)
-        except (TypeError, ValueError, RuntimeError):
-            ten = torch.from_numpy(np.ascontiguousarray(obj).copy())
-        leaves.append(ten)
-        return (_X, len(leaves) - 1)
-    return (_P, obj)
+class _PyLeafSet:
+    """Pure-python twin of _mtc_host.Tree (same methods)."""
+
+    def __init__(self, data: Any):
+        self._leaves: List[torch.Tensor] = []
+        self._spec = self._walk(data)
+        self._outs: List[Optional[torch.Tensor]] = [None] * len(self._leaves)
+
+    def _walk(self, obj):
+        if isinstance(obj, torch.Tensor):
+            self._leaves.append(obj)
+            return (_X, len(self._leaves) - 1)
+        t = type(obj)
+        if t is list:
+            return (_L, [self._walk(o) for o in obj])
+        if t is tuple:
+            return (_T, [self._walk(o) for o in obj])
+        if t is dict:
+            return (_D, list(obj.keys()), [self._walk(o) for o in obj.values()])
+        if isinstance(obj, np.ndarray):
+            try:
+                ten = torch.from_numpy(obj)
+            except (TypeError, ValueError, RuntimeError):
+                ten = torch.from_numpy(np.array(obj, order="C"))
+            self._leaves.append(ten)
+            return (_X, len(self._leaves) - 1)
+        return (_P, obj)
+
+    def num_leaves(self) -> int:
+        return len(self._leaves)
+
+    def leaf(self, i: int) -> torch.Tensor:
+        return self._leaves[i]
+
+    def set_out(self, i: int, t: torch.Tensor) -> None:
+        self._outs[i] = t
+
+    def classify(self, device: str, pack: bool):
+        dev = torch.device(device)
+        n = len(self._leaves)
+        route = np.empty(n, dtype=np.int8)
+        nbytes = np.empty(n, dtype=np.int64)
+        esize = np.empty(n, dtype=np.int32)
+        ptr = np.empty(n, dtype=np.uint64)
+        didx = np.empty(n, dtype=np.int32)
+        for i, t in enumerate(self._leaves):
+            b = t.numel() * t.element_size()
+            nbytes[i], esize[i] = b, t.element_size()
+            ptr[i] = t.data_ptr() if t.numel() else 0
+            didx[i] = -1 if t.device.index is None else t.device.index
+            small = t.is_contiguous() and 0 < b <= PACK_MAX_BYTES_PER_TENSOR
+            if t.device == dev:
+                route[i] = R_REUSE
+                self._outs[i] = t
+            elif t.device.type == "cpu" and dev.type == "cuda":
+                route[i] = R_H2D_PACK if (pack and small) else R_H2D_SINGLE
+            elif t.device.type == "cuda" and dev.type == "cpu":
+                route[i] = R_D2H_SMALL if (pack and small) else R_D2H_OTHER
+            elif t.device.type == "cuda" and dev.type == "cuda":
+                route[i] = R_D2D
+            else:
+                route[i] = R_OTHER
+        return route, nbytes, esize, ptr, didx
+
+    def make_packed_views(self, idx, chunk_of, offsets, chunks, bases) -> None:
+        typed = {}
+        for k in range(len(idx)):
+            t = self._leaves[int(idx[k])]
+            c = int(chunk_of[k])
+            g = chunks[c]
+            key = (c, t.dtype)
+            tv = typed.get(key)
+            if tv is None:
+                base = int(bases[c])
+                usable = (g.numel() - base) // 16 * 16
+                tv = g[base:base + usable].view(t.dtype)
+                typed[key] = tv
+            self._outs[int(idx[k])] = torch.as_strided(tv, t.shape, t.stride(), int(offsets[k]) // t.element_size())
+
+    def rebuild(self):
+        def build(spec):
+            kind = spec[0]
+            if kind == _X:
+                out = self._outs[spec[1]]
+                if out is None:
+                    raise RuntimeError(f"output {spec[1]} was never produced")
+                return out
+            if kind == _P:
+                return spec[1]
+            if kind == _L:
+                return [build(s) for s in spec[1]]
+            if kind == _T:
+                return tuple(build(s) for s in spec[1])
+            return {k: build(s) for k, s in zip(spec[1], spec[2])}
+
+        return build(self._spec)
 
 
-def _rebuild(spec, outs: List[torch.Tensor]):
-    kind = spec[0]
-    if kind == _X:
-        return outs[spec[1]]
-    if kind == _P:
-        return spec[1]
-    if kind == _L:
-        return [_rebuild(s, outs) for s in spec[1]]
-    if kind == _T:
-        return tuple(_rebuild(s, outs) for s in spec[1])
-    return {k: _rebuild(s, outs) for k, s in zip(spec[1], spec[2])}
+def _make_leaf_set(data):
+    if _host is not None and os.environ.get("ACCV_MTC_PY_HOST", "0") != "1":
+        return _host.Tree(data)
+    return _PyLeafSet(data)
 
 
 # ------------------------------------------------------------------------------------------------ job
 class _Job:
     """Everything one start_copy call owns until the handle is consumed."""
 
-    def __init__(self, spec, leaves, device, pinned, pack, min_align, max_chunk):
-        self.spec = spec
-        self.leaves = leaves            # keeps the inputs alive
+    def __init__(self, tree, device, pinned, pack, min_align, max_chunk):
+        self.tree = tree                 # keeps the inputs alive
         self.device = device
         self.pinned = pinned
         self.pack = pack
         self.min_align = max(1, int(min_align))
         self.max_chunk = int(max_chunk)
-        self.outs: List[Optional[torch.Tensor]] = [None] * len(leaves)
+        self.meta = None                 # (route, nbytes, esize, ptr, device index) arrays
         self.events: List[torch.cuda.Event] = []
-        self.staging: List[int] = []    # arena pointers to give back once the DMA is done
-        self.keep: List[Any] = []       # chunk tensors / pinned intermediates
+        self.staging: List[int] = []     # arena pointers to give back once the DMA is done
+        self.keep: List[Any] = []        # chunk tensors / pinned intermediates
         self.caller_stream = None
         self.source_events = {}
         self.released = False
@@ -123,70 +201,58 @@ class _Job:
             self.staging = []
 
 
-def _contig_strides(t: torch.Tensor):
-    return t.stride()
+def _plan(lib, job: _Job, nbytes: np.ndarray, esize: np.ndarray):
+    m = len(nbytes)
+    nbytes = np.ascontiguousarray(nbytes, dtype=np.int64)
+    esize = np.ascontiguousarray(esize, dtype=np.int32)
+    cand = np.ones(m, dtype=np.uint8)
+    off = np.empty(m, dtype=np.int64)
+    chk = np.empty(m, dtype=np.int64)
+    csz = np.empty(max(m, 1), dtype=np.int64)
+    nck = ctypes.c_longlong(0)
+    _nat.check(lib.accv_mtc_plan(m, nbytes.ctypes.data, esize.ctypes.data, cand.ctypes.data, job.min_align, job.max_chunk,
+                                 off.ctypes.data, chk.ctypes.data, csz.ctypes.data, ctypes.addressof(nck)), "mtc_plan")
+    return off, chk, csz, int(nck.value), nbytes
 
 
 def _run(job: _Job) -> None:
     """Orchestration (worker thread or inline): plan, allocate, stage, enqueue, build views."""
-    lib = _nat.lib()
-    dev = job.device
-    leaves = job.leaves
-    n = len(leaves)
+    lib = _nat.lib() if (job.device.type == "cuda" or job.meta[0].max(initial=0) > R_REUSE) else None
+    dev, tree = job.device, job.tree
+    route, nbytes, esize, ptr, didx = job.meta
     to_gpu = dev.type == "cuda"
 
-    h2d_packable, h2d_single, d2h, d2d = [], [], [], []
-    for i, t in enumerate(leaves):
-        if t.device == dev:
-            job.outs[i] = t                      # reuse as is (multi_tensor_copier.cpp:783-786)
-        elif t.device.type == "cpu" and to_gpu:
-            nbytes = t.numel() * t.element_size()
-            if job.pack and t.is_contiguous() and 0 < nbytes <= PACK_MAX_BYTES_PER_TENSOR:
-                h2d_packable.append(i)
-            else:
-                h2d_single.append(i)
-        elif t.device.type == "cuda" and dev.type == "cpu":
-            d2h.append(i)
-        elif t.device.type == "cuda" and to_gpu:
-            d2d.append(i)
-        else:
-            job.outs[i] = t.to(dev)
+    for i in np.nonzero(route == R_OTHER)[0]:
+        tree.set_out(int(i), tree.leaf(int(i)).to(dev))
 
     if to_gpu:
         side = _side_stream(dev)
+        packable = np.nonzero(route == R_H2D_PACK)[0].astype(np.int64)
+        single = np.nonzero(route == R_H2D_SINGLE)[0].tolist()
+        d2d = np.nonzero(route == R_D2D)[0].tolist()
         with torch.cuda.device(dev):
-            # ---- packed host -> GPU
             n_chunks = 0
-            if len(h2d_packable) >= 2:
-                m = len(h2d_packable)
-                nbytes = np.fromiter((leaves[i].numel() * leaves[i].element_size() for i in h2d_packable), np.int64, m)
-                esize = np.fromiter((leaves[i].element_size() for i in h2d_packable), np.int32, m)
-                cand = np.ones(m, dtype=np.uint8)
-                off = np.empty(m, dtype=np.int64)
-                chk = np.empty(m, dtype=np.int64)
-                csz = np.empty(m, dtype=np.int64)
-                nck = ctypes.c_longlong(0)
-                _nat.check(lib.accv_mtc_plan(m, nbytes.ctypes.data, esize.ctypes.data, cand.ctypes.data, job.min_align,
-                                             job.max_chunk, off.ctypes.data, chk.ctypes.data, csz.ctypes.data,
-                                             ctypes.addressof(nck)), "mtc_plan")
-                n_chunks = int(nck.value)
+            if len(packable) >= 2:
+                off, chk, csz, n_chunks, pbytes = _plan(lib, job, nbytes[packable], esize[packable])
             if n_chunks > 0:
+                m = len(packable)
                 align = 16
                 while align < job.min_align:
                     align <<= 1                    # packed_buffer_alignment_bytes, multi_tensor_copier.cpp:399-404
                 order = np.argsort(chk, kind="stable").astype(np.int64)
                 begin = np.searchsorted(chk[order], np.arange(n_chunks + 1)).astype(np.int64)
-                src = np.fromiter((leaves[i].data_ptr() for i in h2d_packable), np.uint64, m)
+                src = np.ascontiguousarray(ptr[packable], dtype=np.uint64)
                 stage_ptrs = np.empty(n_chunks, dtype=np.uint64)
                 dev_ptrs = np.empty(n_chunks, dtype=np.uint64)
+                bases = np.empty(n_chunks, dtype=np.int64)
                 chunks = []
                 with torch.cuda.stream(job.caller_stream):
                     for c in range(n_chunks):
                         size = int(csz[c])
                         g = torch.empty(size + align + 15, dtype=torch.uint8, device=dev)
-                        base = (-g.data_ptr()) % align
-                        chunks.append((g, base))
-                        dev_ptrs[c] = g.data_ptr() + base
+                        bases[c] = (-g.data_ptr()) % align
+                        chunks.append(g)
+                        dev_ptrs[c] = g.data_ptr() + int(bases[c])
                         if job.pinned:
                             p = lib.accv_pinned_acquire(size)
                             if not p:
@@ -200,92 +266,71 @@ def _run(job: _Job) -> None:
                     ready = torch.cuda.Event()
                     ready.record(job.caller_stream)
                 side.wait_event(ready)            # after the caller's work AND after the allocation point
-                _nat.check(lib.accv_mtc_stage_h2d(m, src.ctypes.data, nbytes.ctypes.data, off.ctypes.data,
+                _nat.check(lib.accv_mtc_stage_h2d(m, src.ctypes.data, pbytes.ctypes.data, off.ctypes.data,
                                                   order.ctypes.data, n_chunks, begin.ctypes.data, stage_ptrs.ctypes.data,
                                                   dev_ptrs.ctypes.data, csz.ctypes.data, side.cuda_stream, 0),
                            "mtc_stage_h2d")
                 # typed views into the chunk storage (enqueue_packed_transfer, multi_tensor_copier.cpp:712-729)
-                typed = {}
-                for k, i in enumerate(h2d_packable):
-                    t = leaves[i]
-                    c = int(chk[k])
-                    g, base = chunks[c]
-                    key = (c, t.dtype)
-                    tv = typed.get(key)
-                    if tv is None:
-                        es = t.element_size()
-                        usable = (g.numel() - base) // 16 * 16
-                        tv = g[base:base + usable].view(t.dtype)
-                        typed[key] = tv
-                    job.outs[i] = torch.as_strided(tv, t.shape, t.stride(), int(off[k]) // t.element_size())
+                tree.make_packed_views(packable, chk, off, chunks, bases)
                 job.keep.append(chunks)
             else:
-                h2d_single = sorted(h2d_single + h2d_packable)
+                single = sorted(single + packable.tolist())
             # ---- everything else that targets the GPU goes through torch on the side stream
-            if h2d_single or d2d:
+            if single or d2d:
                 ready = torch.cuda.Event()
                 ready.record(job.caller_stream)
                 side.wait_event(ready)
-                for dev_idx, ev in job.source_events.items():
+                for ev in job.source_events.values():
                     side.wait_event(ev)           # synchronize_source_streams, multi_tensor_copier.cpp:741-762
+                outs = {}
                 with torch.cuda.stream(job.caller_stream):
-                    for i in h2d_single + d2d:
-                        job.outs[i] = torch.empty_like(leaves[i], device=dev)
+                    for i in single + d2d:
+                        outs[i] = torch.empty_like(tree.leaf(i), device=dev)
                 with torch.cuda.stream(side):
-                    for i in h2d_single:
-                        src_t = leaves[i]
+                    for i in single:
+                        src_t = tree.leaf(i)
                         if job.pinned and not src_t.is_pinned():
                             src_t = src_t.contiguous().pin_memory()
                             job.keep.append(src_t)
-                        job.outs[i].copy_(src_t, non_blocking=True)
+                        outs[i].copy_(src_t, non_blocking=True)
                     for i in d2d:
-                        job.outs[i].copy_(leaves[i], non_blocking=True)
+                        outs[i].copy_(tree.leaf(i), non_blocking=True)
+                for i, o in outs.items():
+                    tree.set_out(i, o)
             done = torch.cuda.Event()
             done.record(side)
             job.events.append(done)
-    if d2h:
-        by_dev = {}
-        for i in d2h:
-            by_dev.setdefault(leaves[i].device, []).append(i)
-        for sdev, idxs in by_dev.items():
+    else:
+        d2h_all = np.nonzero((route == R_D2H_SMALL) | (route == R_D2H_OTHER))[0]
+        for dev_index in np.unique(didx[d2h_all]).tolist() if len(d2h_all) else []:
+            sdev = torch.device("cuda", int(dev_index))
             side = _side_stream(sdev)
+            on_dev = d2h_all[didx[d2h_all] == dev_index]
+            small = on_dev[route[on_dev] == R_D2H_SMALL].astype(np.int64)
             with torch.cuda.device(sdev):
-                side.wait_event(job.source_events[sdev.index])
-                small = [i for i in idxs if job.pack and leaves[i].is_contiguous()
-                         and 0 < leaves[i].numel() * leaves[i].element_size() <= PACK_MAX_BYTES_PER_TENSOR]
-                packed_ok = False
-                if len(small) >= 2:
-                    packed_ok = _coalesced_d2h(job, lib, small, sdev, side)
-                rest = [i for i in idxs if not (packed_ok and i in set(small))]
+                side.wait_event(job.source_events[int(dev_index)])
+                packed_ok = len(small) >= 2 and _coalesced_d2h(job, lib, small, sdev, side)
+                rest = on_dev.tolist() if not packed_ok else on_dev[route[on_dev] == R_D2H_OTHER].tolist()
                 with torch.cuda.stream(side):
                     for i in rest:
-                        t = leaves[i]
+                        t = tree.leaf(i)
                         out = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=job.pinned)
                         out.copy_(t, non_blocking=job.pinned)
-                        job.outs[i] = out
+                        tree.set_out(i, out)
                 done = torch.cuda.Event()
                 done.record(side)
                 job.events.append(done)
 
 
-def _coalesced_d2h(job: _Job, lib, small: List[int], sdev: torch.device, side) -> bool:
+def _coalesced_d2h(job: _Job, lib, small: np.ndarray, sdev: torch.device, side) -> bool:
     """Many small device tensors -> ONE device gather kernel (accv_mtc_coalesce) -> ONE D2H transfer per chunk -> host
     views (the reference copies each tensor separately, multi_tensor_copier.cpp:790-800)."""
-    leaves = job.leaves
-    m = len(small)
-    nbytes = np.fromiter((leaves[i].numel() * leaves[i].element_size() for i in small), np.int64, m)
-    esize = np.fromiter((leaves[i].element_size() for i in small), np.int32, m)
-    off = np.empty(m, dtype=np.int64)
-    chk = np.empty(m, dtype=np.int64)
-    csz = np.empty(m, dtype=np.int64)
-    nck = ctypes.c_longlong(0)
-    _nat.check(lib.accv_mtc_plan(m, nbytes.ctypes.data, esize.ctypes.data, np.ones(m, dtype=np.uint8).ctypes.data,
-                                 job.min_align, job.max_chunk, off.ctypes.data, chk.ctypes.data, csz.ctypes.data,
-                                 ctypes.addressof(nck)), "mtc_plan")
-    n_chunks = int(nck.value)
+    route, nbytes, esize, ptr, _ = job.meta
+    off, chk, csz, n_chunks, sbytes = _plan(lib, job, nbytes[small], esize[small])
     if n_chunks == 0:
         return False
-    ptrs = np.fromiter((leaves[i].data_ptr() for i in small), np.uint64, m)
+    ptrs = np.ascontiguousarray(ptr[small], dtype=np.uint64)
+    hosts, bases = [], np.zeros(n_chunks, dtype=np.int64)
     with torch.cuda.stream(side):
         for c in range(n_chunks):
             sel = np.nonzero(chk == c)[0]
@@ -293,22 +338,16 @@ def _coalesced_d2h(job: _Job, lib, small: List[int], sdev: torch.device, side) -
             table = np.empty((len(sel), 3), dtype=np.int64)      # {src pointer, offset in packed, nbytes}
             table[:, 0] = ptrs[sel].view(np.int64)
             table[:, 1] = off[sel]
-            table[:, 2] = nbytes[sel]
-            items = torch.from_numpy(table).to(sdev, non_blocking=False)
+            table[:, 2] = sbytes[sel]
+            items = torch.from_numpy(table).to(sdev)
             packed = torch.empty(size + 16, dtype=torch.uint8, device=sdev)
             _nat.check(lib.accv_mtc_coalesce(items.data_ptr(), len(sel), packed.data_ptr(), 0, side.cuda_stream),
                        "mtc_coalesce")
-            host = torch.empty(size + 16, dtype=torch.uint8, device="cpu", pin_memory=job.pinned)
-            host.copy_(packed, non_blocking=job.pinned)
+            host = torch.empty((size + 31) // 16 * 16, dtype=torch.uint8, device="cpu", pin_memory=job.pinned)
+            host[:size + 16].copy_(packed, non_blocking=job.pinned)
             job.keep.append((items, packed))
-            typed = {}
-            for k in sel:
-                t = leaves[small[k]]
-                tv = typed.get(t.dtype)
-                if tv is None:
-                    tv = host[: (size + 15) // 16 * 16].view(t.dtype)
-                    typed[t.dtype] = tv
-                job.outs[small[k]] = torch.as_strided(tv, t.shape, t.stride(), int(off[k]) // t.element_size())
+            hosts.append(host)
+    job.tree.make_packed_views(small, chk, off, hosts, bases)
     return True
 
 
@@ -345,7 +384,7 @@ class AsyncCopyHandle:
         """Block until done; return the input structure with every tensor on the target device."""
         if not self._consumed:
             self._finish()
-            self._result = _rebuild(self._job.spec, self._job.outs)
+            self._result = self._job.tree.rebuild()
             self._consumed = True
         return self._result
 
@@ -368,8 +407,8 @@ def start_copy(data, device, *, use_pinned_staging: bool = True, pack_cpu_tensor
         device: target device (``"cuda:0"``, ``"cpu"``, ``torch.device``).
         use_pinned_staging: stage host<->GPU transfers through pinned memory (host->GPU becomes asynchronous;
             GPU->host returns the pinned buffer itself).
-        pack_cpu_tensors: coalesce small contiguous host tensors (<= 256 KiB each, any dtype mix) into shared chunks
-            with one transfer per chunk.  Only for host->GPU.
+        pack_cpu_tensors: coalesce small contiguous tensors (<= 256 KiB each, any dtype mix) into shared chunks with one
+            transfer per chunk (host->GPU as in the reference; also applied to GPU->host here).
         min_packed_alignment_bytes: each packed tensor starts at a multiple of
             ``round_up(max(min_packed_alignment_bytes, element_size), element_size)`` inside its chunk.
         max_packed_chunk_bytes: payload limit per chunk (default 32 MiB).
@@ -386,18 +425,18 @@ def start_copy(data, device, *, use_pinned_staging: bool = True, pack_cpu_tensor
         _nat.lib()  # fail loudly if the HIP library is missing
     elif dev.type != "cpu":
         raise RuntimeError(f"Invalid device string: {device!r}")
-    leaves: List[torch.Tensor] = []
-    spec = _flatten(data, leaves)
-    job = _Job(spec, leaves, dev, bool(use_pinned_staging), bool(pack_cpu_tensors), int(min_packed_alignment_bytes),
+    tree = _make_leaf_set(data)
+    job = _Job(tree, dev, bool(use_pinned_staging), bool(pack_cpu_tensors), int(min_packed_alignment_bytes),
                int(max_packed_chunk_bytes))
+    job.meta = tree.classify(str(dev), job.pack)
+    route, _, _, _, didx = job.meta
     # ordering: capture the caller's current streams NOW (reference :1086-1123)
     if dev.type == "cuda":
         job.caller_stream = torch.cuda.current_stream(dev)
-    for t in leaves:
-        if t.device.type == "cuda" and t.device != dev and t.device.index not in job.source_events:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(t.device))
-            job.source_events[t.device.index] = ev
+    for dev_index in np.unique(didx[(route >= R_D2H_SMALL) & (route <= R_D2D)]).tolist():
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(torch.device("cuda", int(dev_index))))
+        job.source_events[int(dev_index)] = ev
     if use_background_thread:
         return AsyncCopyHandle(job, _executor().submit(_run, job))
     _run(job)  # inline: exceptions propagate from start_copy (reference :1151-1153)

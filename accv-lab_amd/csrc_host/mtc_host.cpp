@@ -1,0 +1,210 @@
+// Host-side fast path of accvlab.multi_tensor_copier: tree walk, leaf classification, packed-view construction and
+// output rebuild in C++ (pybind11 + ATen), so that a start_copy() over thousands of leaves costs O(1) python calls.
+// Plumbing only — no device code, no HIP calls; staging / planning / transfers stay behind the C-ABI
+// (include/accv_hip.h), streams and events stay in python.
+//
+// Behavioural counterpart of the reference's Node / traverse_build_tree_impl / rebuild logic
+// (packages/multi_tensor_copier/accvlab/multi_tensor_copier/csrc/multi_tensor_copier.cpp:50-72, 163-221, 978-1005);
+// the representation is different: a flat pre-order op list instead of a node tree.
+#include <pybind11/numpy.h>
+#include <pybind11/stl.h>
+#include <torch/extension.h>
+
+#include <cstdint>
+#include <vector>
+
+namespace py = pybind11;
+
+namespace {
+
+constexpr int64_t kPackMaxBytes = 256 * 1024;  // multi_tensor_copier.cpp:483
+
+enum Kind : uint8_t { kList = 0, kTuple = 1, kDict = 2, kLeaf = 3, kPass = 4 };
+
+// classification of a leaf relative to the target device
+enum Route : int8_t { kReuse = 0, kH2DPack = 1, kH2DSingle = 2, kD2HSmall = 3, kD2HOther = 4, kD2D = 5, kOther = 6 };
+
+struct Op {
+    uint8_t kind;
+    int64_t arg;  // containers: number of children; leaf: leaf index; pass: index into objects
+};
+
+class Tree {
+public:
+    explicit Tree(const py::object& data)
+    {
+        from_numpy_ = py::module_::import("torch").attr("from_numpy");
+        ndarray_type_ = py::module_::import("numpy").attr("ndarray");
+        walk(data);
+        outs_.resize(leaves_.size());
+    }
+
+    int64_t num_leaves() const { return (int64_t)leaves_.size(); }
+    at::Tensor leaf(int64_t i) const { return leaves_.at((size_t)i); }
+    void set_out(int64_t i, const at::Tensor& t) { outs_.at((size_t)i) = t; }
+
+    // (route int8[n], nbytes int64[n], elem_size int32[n], data_ptr uint64[n], device_index int32[n])
+    py::tuple classify(const std::string& device, bool pack)
+    {
+        const at::Device target(device);
+        const int64_t n = num_leaves();
+        py::array_t<int8_t> route(n);
+        py::array_t<int64_t> nbytes(n);
+        py::array_t<int32_t> esize(n);
+        py::array_t<uint64_t> ptr(n);
+        py::array_t<int32_t> dev(n);
+        auto r = route.mutable_unchecked<1>();
+        auto b = nbytes.mutable_unchecked<1>();
+        auto e = esize.mutable_unchecked<1>();
+        auto p = ptr.mutable_unchecked<1>();
+        auto d = dev.mutable_unchecked<1>();
+        for (int64_t i = 0; i < n; ++i) {
+            const at::Tensor& t = leaves_[(size_t)i];
+            const int64_t bytes = t.numel() * (int64_t)t.element_size();
+            b(i) = bytes;
+            e(i) = (int32_t)t.element_size();
+            p(i) = (uint64_t) reinterpret_cast<uintptr_t>(t.numel() ? t.data_ptr() : nullptr);
+            d(i) = t.device().has_index() ? (int32_t)t.device().index() : -1;
+            const bool small = t.is_contiguous() && bytes > 0 && bytes <= kPackMaxBytes;
+            int8_t k;
+            if (t.device() == target) {
+                k = kReuse;
+                outs_[(size_t)i] = t;  // reuse as is
+            } else if (t.device().is_cpu() && target.is_cuda()) {
+                k = (pack && small) ? kH2DPack : kH2DSingle;
+            } else if (t.device().is_cuda() && target.is_cpu()) {
+                k = (pack && small) ? kD2HSmall : kD2HOther;
+            } else if (t.device().is_cuda() && target.is_cuda()) {
+                k = kD2D;
+            } else {
+                k = kOther;
+            }
+            r(i) = k;
+        }
+        return py::make_tuple(route, nbytes, esize, ptr, dev);
+    }
+
+    // typed views into packed chunk storages: out[idx[k]] aliases chunks[chunk_of[k]] at byte (base[c] + offset[k])
+    void make_packed_views(const py::array_t<int64_t>& idx, const py::array_t<int64_t>& chunk_of,
+                           const py::array_t<int64_t>& offsets, const std::vector<at::Tensor>& chunks,
+                           const py::array_t<int64_t>& bases)
+    {
+        auto ix = idx.unchecked<1>();
+        auto ck = chunk_of.unchecked<1>();
+        auto of = offsets.unchecked<1>();
+        auto bs = bases.unchecked<1>();
+        for (py::ssize_t k = 0; k < ix.shape(0); ++k) {
+            const at::Tensor& t = leaves_.at((size_t)ix(k));
+            const at::Tensor& chunk = chunks.at((size_t)ck(k));
+            const int64_t es = (int64_t)t.element_size();
+            const int64_t byte_off = chunk.storage_offset() + bs(ck(k)) + of(k);
+            TORCH_CHECK(byte_off % es == 0, "packed offset ", byte_off, " is not a multiple of the element size ", es);
+            at::Tensor out = at::empty({0}, t.options().device(chunk.device()));
+            out.set_(chunk.storage(), byte_off / es, t.sizes(), t.strides());
+            outs_[(size_t)ix(k)] = out;
+        }
+    }
+
+    py::object rebuild() const
+    {
+        size_t cursor = 0;
+        return build(cursor);
+    }
+
+private:
+    void walk(const py::handle& obj)
+    {
+        PyObject* raw = obj.ptr();
+        if (THPVariable_Check(raw)) {
+            ops_.push_back({kLeaf, (int64_t)leaves_.size()});
+            leaves_.push_back(THPVariable_Unpack(raw));
+        } else if (PyList_CheckExact(raw)) {
+            const py::ssize_t n = PyList_GET_SIZE(raw);
+            ops_.push_back({kList, (int64_t)n});
+            for (py::ssize_t i = 0; i < n; ++i) walk(PyList_GET_ITEM(raw, i));
+        } else if (PyTuple_CheckExact(raw)) {
+            const py::ssize_t n = PyTuple_GET_SIZE(raw);
+            ops_.push_back({kTuple, (int64_t)n});
+            for (py::ssize_t i = 0; i < n; ++i) walk(PyTuple_GET_ITEM(raw, i));
+        } else if (PyDict_CheckExact(raw)) {
+            ops_.push_back({kDict, (int64_t)PyDict_Size(raw)});
+            PyObject *key, *value;
+            Py_ssize_t pos = 0;
+            while (PyDict_Next(raw, &pos, &key, &value)) {
+                objects_.push_back(py::reinterpret_borrow<py::object>(key));
+                walk(value);
+            }
+        } else if (py::isinstance(obj, ndarray_type_)) {
+            py::object ten;
+            try {
+                ten = from_numpy_(obj);
+            } catch (py::error_already_set&) {  // read-only / negative-stride arrays: take a contiguous copy
+                ten = from_numpy_(py::module_::import("numpy").attr("array")(obj, py::arg("order") = "C"));
+            }
+            ops_.push_back({kLeaf, (int64_t)leaves_.size()});
+            leaves_.push_back(THPVariable_Unpack(ten.ptr()));
+        } else {
+            ops_.push_back({kPass, (int64_t)objects_.size()});
+            objects_.push_back(py::reinterpret_borrow<py::object>(obj));
+        }
+    }
+
+    // dict keys were pushed in traversal order interleaved with passthrough objects: replay the same order
+    py::object build(size_t& cursor) const
+    {
+        size_t obj_cursor = 0;
+        return build_rec(cursor, obj_cursor);
+    }
+    py::object build_rec(size_t& cursor, size_t& obj_cursor) const
+    {
+        const Op op = ops_.at(cursor++);
+        switch (op.kind) {
+            case kLeaf: {
+                const at::Tensor& t = outs_.at((size_t)op.arg);
+                TORCH_CHECK(t.defined(), "output ", op.arg, " was never produced");
+                return py::reinterpret_steal<py::object>(THPVariable_Wrap(t));
+            }
+            case kPass:
+                return objects_.at(obj_cursor++);
+            case kList: {
+                py::list out((py::ssize_t)op.arg);
+                for (int64_t i = 0; i < op.arg; ++i) out[(py::ssize_t)i] = build_rec(cursor, obj_cursor);
+                return std::move(out);
+            }
+            case kTuple: {
+                py::tuple out((py::ssize_t)op.arg);
+                for (int64_t i = 0; i < op.arg; ++i) out[(py::ssize_t)i] = build_rec(cursor, obj_cursor);
+                return std::move(out);
+            }
+            default: {
+                py::dict out;
+                for (int64_t i = 0; i < op.arg; ++i) {
+                    py::object key = objects_.at(obj_cursor++);
+                    out[key] = build_rec(cursor, obj_cursor);
+                }
+                return std::move(out);
+            }
+        }
+    }
+
+    std::vector<Op> ops_;
+    std::vector<at::Tensor> leaves_;
+    std::vector<at::Tensor> outs_;
+    std::vector<py::object> objects_;  // dict keys and passthrough leaves, in traversal order
+    py::object from_numpy_, ndarray_type_;
+};
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "host fast path of accvlab.multi_tensor_copier (tree walk / classification / views / rebuild)";
+    py::class_<Tree>(m, "Tree")
+        .def(py::init<const py::object&>())
+        .def("num_leaves", &Tree::num_leaves)
+        .def("leaf", &Tree::leaf)
+        .def("set_out", &Tree::set_out)
+        .def("classify", &Tree::classify)
+        .def("make_packed_views", &Tree::make_packed_views)
+        .def("rebuild", &Tree::rebuild);
+}

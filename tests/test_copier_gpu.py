@@ -18,6 +18,16 @@ def _mtc():
     return mtc
 
 
+@pytest.fixture(autouse=True, params=["cpp-host", "py-host"])
+def host_path(request, monkeypatch):
+    """every test runs with the C++ host module (_mtc_host) and with its pure-python twin"""
+    monkeypatch.setenv("ACCV_MTC_PY_HOST", "1" if request.param == "py-host" else "0")
+    if request.param == "cpp-host":
+        from accvlab.multi_tensor_copier import copier
+        assert copier._host is not None, "build the host extension (make -C accv-lab_amd/csrc_host)"
+    yield
+
+
 def _storage_ptr(t):
     return t.untyped_storage().data_ptr()
 
