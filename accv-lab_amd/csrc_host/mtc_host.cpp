@@ -99,9 +99,11 @@ public:
             const int64_t es = (int64_t)t.element_size();
             const int64_t byte_off = chunk.storage_offset() + bs(ck(k)) + of(k);
             TORCH_CHECK(byte_off % es == 0, "packed offset ", byte_off, " is not a multiple of the element size ", es);
-            at::Tensor out = at::empty({0}, t.options().device(chunk.device()));
-            out.set_(chunk.storage(), byte_off / es, t.sizes(), t.strides());
-            outs_[(size_t)ix(k)] = out;
+            // build the view directly on the chunk's storage (no intermediate empty tensor + set_)
+            auto impl = c10::make_intrusive<at::TensorImpl>(c10::Storage(chunk.storage()), chunk.key_set(), t.dtype());
+            impl->set_sizes_and_strides(t.sizes(), t.strides());
+            impl->set_storage_offset(byte_off / es);
+            outs_[(size_t)ix(k)] = at::Tensor(std::move(impl));
         }
     }
 
