@@ -173,6 +173,28 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
         const unsigned long long m = __ballot(hit);
         const int nh = __popcll(m);
         if (nh == 0) continue;
+        if constexpr (!CLEAR) {
+            // in-place: the tile is touched -> fetch its current content into the accumulators NOW, so the load
+            // latency hides behind the table and accumulate phases (max is order independent)
+            if (total_hits == 0 && col0 < p.W) {
+                const float* plane_rd = p.hm + (size_t)plane * (size_t)p.H * (size_t)p.W;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int row = ty0 + sub * R + i;
+                    if (row < p.H) {
+                        if constexpr (PX == 4) {
+                            const vfloat4 o = *reinterpret_cast<const vfloat4*>(plane_rd + (size_t)row * p.W + col0);
+                            acc[i][0] = o.x;
+                            acc[i][1] = o.y;
+                            acc[i][2] = o.z;
+                            acc[i][3] = o.w;
+                        } else {
+                            acc[i][0] = plane_rd[(size_t)row * p.W + col0];
+                        }
+                    }
+                }
+            }
+        }
         if (hit) {
             const int pos = __popcll(m & ((1ull << lane) - 1ull));
             const float sigma = (float)(2 * r + 1) / p.factor;
@@ -233,20 +255,10 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
         if (row >= p.H) break;
         V* dst = reinterpret_cast<V*>(plane_ptr + (size_t)row * p.W + col0);
         V out;
-        if constexpr (PX == 4) {
-            if constexpr (!CLEAR) {
-                const V old = *dst;
-                out = V{fmaxf(old.x, acc[i][0]), fmaxf(old.y, acc[i][1]), fmaxf(old.z, acc[i][2]),
-                        fmaxf(old.w, acc[i][3])};
-            } else {
-                out = V{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-            }
-        } else {
-            if constexpr (!CLEAR)
-                out = fmaxf(*dst, acc[i][0]);
-            else
-                out = acc[i][0];
-        }
+        if constexpr (PX == 4)
+            out = V{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};  // in-place mode: acc already holds max(old, splats)
+        else
+            out = acc[i][0];
         if constexpr (SM == 1) {
             __builtin_nontemporal_store(out, dst);
         } else if constexpr (SM >= 2 && PX == 4) {
