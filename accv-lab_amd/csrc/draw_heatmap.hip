@@ -44,9 +44,7 @@ struct SplatParams {
     long long n_tiles;
     float factor, k;
     int counts_i64;
-    int plane_minor;      // tile order: 0 = plane-major (tiles of a plane adjacent), 1 = planes interleaved
     int grid3d;           // tile index comes from a 3-D grid instead of a linear block index
-    long long n_planes;
 };
 
 struct __attribute__((aligned(16))) HitX {  // column side of a hit, read as one ds_read_b128 broadcast
@@ -74,12 +72,12 @@ struct Vec<1> {
 
 __device__ __forceinline__ float raw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <int PX, int R, bool CLEAR, int SM, int WPG = kWavesPerGroup, int LPR = 32>
+template <int PX, int R, bool CLEAR, int SM, int WPG = kWavesPerGroup>
 __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
 {
     constexpr int kWavesPerGroup = WPG;  // shadows the namespace constant inside the kernel
-    constexpr int TW = LPR * PX;         // LPR lanes side by side cover one row segment of the tile
-    constexpr int TH = (64 / LPR) * R;   // the 64/LPR lane groups take R rows each
+    constexpr int TW = 32 * PX;  // 32 lanes side by side cover one row segment of the tile
+    constexpr int TH = 2 * R;    // the two half-waves take R rows each
     static_assert(R % 4 == 0, "row registers are fetched four at a time");
 
     __shared__ HitX s_hx[kWavesPerGroup][kCand];
@@ -96,25 +94,13 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
         ty = blockIdx.y;
         plane = blockIdx.z;
         if (tx >= p.tiles_x) return;
-    } else {
+    } else {  // linear block index (more than 65535 planes or tile rows)
         const long long tile = (long long)blockIdx.x * kWavesPerGroup + wave;
         if (tile >= p.n_tiles) return;  // whole wave exits; waves never synchronise with each other
-        if (p.plane_minor) {
-            // groups of kWavesPerGroup column tiles stay together; planes vary fastest across workgroups
-            const long long grp = tile / kWavesPerGroup;
-            const int w = (int)(tile - grp * kWavesPerGroup);
-            plane = grp % p.n_planes;
-            const long long rest = grp / p.n_planes;
-            const int gx = (p.tiles_x + kWavesPerGroup - 1) / kWavesPerGroup;
-            tx = (int)(rest % gx) * kWavesPerGroup + w;
-            ty = (int)(rest / gx);
-            if (tx >= p.tiles_x || ty >= p.tiles_y) return;
-        } else {
-            tx = (int)(tile % p.tiles_x);
-            const long long t2 = tile / p.tiles_x;
-            ty = (int)(t2 % p.tiles_y);
-            plane = t2 / p.tiles_y;
-        }
+        tx = (int)(tile % p.tiles_x);
+        const long long t2 = tile / p.tiles_x;
+        ty = (int)(t2 % p.tiles_y);
+        plane = t2 / p.tiles_y;
     }
 
     const int tx0 = tx * TW, ty0 = ty * TH;
@@ -139,8 +125,8 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
         obj_base = s * p.n_max;
     }
 
-    const int sub = lane / LPR;        // which lane group: rows [sub*R, sub*R + R) of the tile
-    const int col0 = tx0 + (lane % LPR) * PX;
+    const int sub = lane >> 5;  // which half-wave: rows [sub*R, sub*R + R) of the tile
+    const int col0 = tx0 + (lane & 31) * PX;
 
     float acc[R][PX];
     const float init = CLEAR ? 0.0f : __builtin_nanf("");
@@ -262,8 +248,8 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
         if constexpr (SM == 1) {
             __builtin_nontemporal_store(out, dst);
         } else if constexpr (SM >= 2 && PX == 4) {
-            // cache-policy experiments: raw buffer store with aux bits (16 = sc1 write-through, 1 = sc0, 2 = nt)
-            constexpr int aux = SM == 2 ? 16 : SM == 3 ? 17 : SM == 4 ? 18 : SM == 5 ? 19 : SM == 6 ? 0 : 2;
+            // write-through (sc1) / write-through non-temporal (sc1 nt) 16-byte buffer store
+            constexpr int aux = SM == 2 ? 16 : 18;  // sc1 | sc1+nt
             const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b128(out, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, aux);
         } else {
@@ -411,7 +397,7 @@ __global__ __launch_bounds__(NW * 64) void splat_rows_kernel(const SplatParams p
         out = vfloat4{acc[0], acc[1], acc[2], acc[3]};
     }
     if constexpr (SM >= 2) {
-        constexpr int aux = SM == 2 ? 16 : SM == 3 ? 17 : SM == 4 ? 18 : SM == 5 ? 19 : SM == 6 ? 0 : 2;
+        constexpr int aux = SM == 2 ? 16 : 18;  // sc1 | sc1+nt
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(out, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, aux);
     } else if constexpr (SM == 1) {
@@ -439,7 +425,6 @@ int launch_splat_rows(SplatParams p, long long planes, bool clear, int sm, hipSt
     switch (sm) {
         case 2: ACCV_LAUNCH_ROWS(2); break;
         case 4: ACCV_LAUNCH_ROWS(4); break;
-        case 6: ACCV_LAUNCH_ROWS(6); break;
         default: ACCV_LAUNCH_ROWS(0); break;
     }
 #undef ACCV_LAUNCH_ROWS
@@ -523,43 +508,35 @@ __global__ void fill_tail_kernel(float* __restrict__ dst, size_t n, float value)
     if (i < n) dst[i] = value;
 }
 
-template <int PX, int R, int WPG = kWavesPerGroup, int LPR = 32>
-int launch_splat(SplatParams p, long long planes, bool clear, int nt, hipStream_t stream)
+template <int PX, int R, int WPG = kWavesPerGroup>
+int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_t stream)
 {
-    constexpr int kWavesPerGroup = WPG;
-    p.tiles_x = (p.W + LPR * PX - 1) / (LPR * PX);
-    p.tiles_y = (p.H + (64 / LPR) * R - 1) / ((64 / LPR) * R);
+    p.tiles_x = (p.W + 32 * PX - 1) / (32 * PX);
+    p.tiles_y = (p.H + 2 * R - 1) / (2 * R);
     p.n_tiles = planes * p.tiles_x * p.tiles_y;
-    p.n_planes = planes;
-    p.plane_minor = accv::tune_get("hm_order", 0);
-    if (p.plane_minor) {
-        const long long gx = (p.tiles_x + kWavesPerGroup - 1) / kWavesPerGroup;
-        p.n_tiles = planes * gx * kWavesPerGroup * p.tiles_y;
+    if (p.n_tiles == 0) return ACCV_OK;
+    const int groups_x = (p.tiles_x + WPG - 1) / WPG;
+    dim3 grid, block(WPG * 64);
+    p.grid3d = (planes <= 65535 && p.tiles_y <= 65535) ? 1 : 0;
+    if (p.grid3d) {
+        grid = dim3((unsigned)groups_x, (unsigned)p.tiles_y, (unsigned)planes);
+    } else {
+        const long long groups = (p.n_tiles + WPG - 1) / WPG;
+        if (groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap: %lld tiles exceed the grid limit", p.n_tiles);
+        grid = dim3((unsigned)groups);
     }
-    const size_t lds_pad = (size_t)accv::tune_get("hm_lds_pad_kb", 0) * 1024;
-    const long long groups = (p.n_tiles + kWavesPerGroup - 1) / kWavesPerGroup;
-    if (groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap: %lld tiles exceed the grid limit", p.n_tiles);
-    if (groups == 0) return ACCV_OK;
-    dim3 grid((unsigned)groups), block(kWavesPerGroup * 64);
-    p.grid3d = (!p.plane_minor && planes <= 65535 && p.tiles_y <= 65535 && accv::tune_get("hm_grid3d", 1)) ? 1 : 0;
-    if (p.grid3d) grid = dim3((unsigned)((p.tiles_x + kWavesPerGroup - 1) / kWavesPerGroup), (unsigned)p.tiles_y, (unsigned)planes);
-    const int sm = nt;  // store mode: 0 plain, 1 nontemporal, 2 sc1, 3 sc0+sc1, 4 sc1+nt
-#define ACCV_LAUNCH_SM(SMV)                                                                                        \
-    do {                                                                                                           \
-        if (clear)                                                                                                 \
-            hipLaunchKernelGGL((splat_kernel<PX, R, true, SMV, WPG, LPR>), grid, block, lds_pad, stream, p);       \
-        else                                                                                                       \
-            hipLaunchKernelGGL((splat_kernel<PX, R, false, SMV, WPG, LPR>), grid, block, lds_pad, stream, p);      \
+#define ACCV_LAUNCH_SM(SMV)                                                                              \
+    do {                                                                                                 \
+        if (clear)                                                                                       \
+            hipLaunchKernelGGL((splat_kernel<PX, R, true, SMV, WPG>), grid, block, 0, stream, p);        \
+        else                                                                                             \
+            hipLaunchKernelGGL((splat_kernel<PX, R, false, SMV, WPG>), grid, block, 0, stream, p);       \
     } while (0)
-    if constexpr (PX == 4 && (WPG == 1 || (WPG == 4 && R == 8 && LPR == 32))) {
-        switch (sm) {
+    if constexpr (PX == 4) {
+        switch (sm) {  // store mode: 0 plain, 1 non-temporal, 2 write-through (sc1), 4 write-through non-temporal
             case 1: ACCV_LAUNCH_SM(1); break;
             case 2: ACCV_LAUNCH_SM(2); break;
-            case 3: ACCV_LAUNCH_SM(3); break;
             case 4: ACCV_LAUNCH_SM(4); break;
-            case 5: ACCV_LAUNCH_SM(5); break;
-            case 6: ACCV_LAUNCH_SM(6); break;
-            case 7: ACCV_LAUNCH_SM(7); break;
             default: ACCV_LAUNCH_SM(0); break;
         }
     } else {
@@ -580,34 +557,20 @@ int dispatch_splat(const SplatParams& p, long long planes, bool clear, hipStream
     int nt = accv::tune_get("hm_nt", -1);
     if (nt < 0) nt = (total_bytes > ((size_t)128 << 20) && plane_fits_rsrc) ? 4 : 0;
     if (nt >= 2 && !plane_fits_rsrc) nt = 0;
-    const int rows = accv::tune_get("hm_rows", 8);
+    // tuning knobs exist for in-process A/B runs (scripts/h1_variants.py); the defaults are the shipped configuration
     const int kernel = accv::tune_get("hm_kernel", 1);
     // the row-pair kernel addresses objects/planes with 32-bit math and a 3-D grid
     const bool fits32 = planes <= 65535 && (long long)planes * std::max(p.n_max, 1) < (1ll << 31) &&
                         (p.H + 7) / 8 <= 65535;
     if (vec4 && kernel == 2 && fits32) {
-        const int nw = accv::tune_get("hm_nw", 16);
-        if (nw == 8) return launch_splat_rows<8>(p, planes, clear, nt, stream);
-        if (nw == 4) return launch_splat_rows<4>(p, planes, clear, nt, stream);
+        if (accv::tune_get("hm_nw", 16) == 8) return launch_splat_rows<8>(p, planes, clear, nt, stream);
         return launch_splat_rows<16>(p, planes, clear, nt, stream);
     }
+    if (!vec4) return launch_splat<1, 8>(p, planes, clear, 0, stream);
     const int wpg = accv::tune_get("hm_wpg", kWavesPerGroup);
-    if (vec4) {
-        if (rows == 16 && accv::tune_get("hm_lpr", 32) != 64) return launch_splat<4, 16>(p, planes, clear, nt, stream);
-        if (rows == 4) {
-            if (wpg == 4) return launch_splat<4, 4, 4>(p, planes, clear, nt, stream);
-            return launch_splat<4, 4>(p, planes, clear, nt, stream);
-        }
-        if (accv::tune_get("hm_lpr", 32) == 64) {
-            if (rows == 16) return launch_splat<4, 16, 1, 64>(p, planes, clear, nt, stream);
-            return launch_splat<4, 8, 1, 64>(p, planes, clear, nt, stream);
-        }
-        if (wpg == 4) return launch_splat<4, 8, 4>(p, planes, clear, nt, stream);
-        if (wpg == 2) return launch_splat<4, 8, 2>(p, planes, clear, nt, stream);
-        if (wpg == 8) return launch_splat<4, 8, 8>(p, planes, clear, nt, stream);
-        return launch_splat<4, 8>(p, planes, clear, nt, stream);
-    }
-    return launch_splat<1, 8>(p, planes, clear, nt, stream);
+    if (accv::tune_get("hm_rows", 8) == 16) return launch_splat<4, 16>(p, planes, clear, nt, stream);
+    if (wpg == 4) return launch_splat<4, 8, 4>(p, planes, clear, nt, stream);
+    return launch_splat<4, 8>(p, planes, clear, nt, stream);
 }
 
 int check_common(const void* hm, int h, int w, float factor, const char* who)

@@ -23,7 +23,8 @@ def main():
     ap.add_argument("--rule", default="A")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--knobs", default="hm_rows=8,16,4;hm_nt=0,1")
+    ap.add_argument("--knobs", default="hm_wpg=1,4;hm_nt=0,4",
+                    help="knobs understood by libaccv_hip: hm_kernel=1|2, hm_nw=16|8, hm_wpg=1|4, hm_rows=8|16, hm_nt=0|1|2|4")
     ap.add_argument("--empty", action="store_true", help="no objects: isolates the store pattern")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
