@@ -7,7 +7,7 @@ One "step" = one fused clear+draw of the whole batch through the public operator
 ``accvlab.draw_heatmap.draw_heatmap_batched(..., clear=True)`` -> C-ABI -> one HIP kernel launch, with the
 object lists already resident in HBM.  Prints ONE JSON line on rank 0.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 500 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -63,8 +63,8 @@ def cpu_baseline(centers_l, radii_l, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU")
     ap.add_argument("--rule", default="A", choices=["A", "B"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -326,3 +326,43 @@ def test_target_prep_front_end_gpu_bit_exact_and_multi_scale():
         ref = np.zeros((B, SH // s, SW // s), dtype=np.float32)
         oracle.draw_heatmap_batched(ref, ci_cpu.numpy(), ri_cpu.numpy(), sizes.numpy(), clear=True)
         _close(hm, ref, f"multi-scale stride {s}")
+
+
+def test_full_size_equivalences_and_scaling():
+    """BASELINE-sized (1080x1920) properties that need no oracle: the three entry points are bitwise identical on the
+    same objects (max is order independent and they share the per-object arithmetic); the map scales with k; adding
+    objects never lowers a pixel."""
+    draw_heatmap, draw_heatmap_batched = _dh()
+    B, H, W = 6, 1080, 1920
+    cl, rl = wl.heatmap_objects(B, H, W, 1, 128, "A", seed=77)
+    cpad, sizes = wl.pad_ragged(cl)
+    rpad, _ = wl.pad_ragged(rl)
+    c, r = rb(cpad.to(DEV), sizes.to(DEV)), rb(rpad.to(DEV), sizes.to(DEV))
+    a = torch.empty((B, H, W), device=DEV)
+    draw_heatmap_batched(a, c, r, clear=True)
+    # flat with shuffled object order
+    cf, rf, idx = _flat_from_padded(cpad.numpy(), rpad.numpy(), sizes.numpy())
+    perm = np.random.RandomState(0).permutation(len(rf))
+    f = torch.zeros((B, H, W), device=DEV)
+    draw_heatmap(f, _t(cf[perm]), _t(rf[perm]), _t(idx[perm]))
+    assert torch.equal(a, f)
+    # class-wise with every label == 2 lands in plane 2 only
+    labels = rb(torch.full_like(rpad, 2).to(DEV), sizes.to(DEV))
+    cw = torch.empty((B, 3, H, W), device=DEV)
+    draw_heatmap_batched(cw, c, r, labels=labels, clear=True)
+    assert torch.equal(cw[:, 2], a) and float(cw[:, :2].abs().max()) == 0.0
+    # scaling in k
+    half = torch.empty_like(a)
+    draw_heatmap_batched(half, c, r, 6.0, 0.5, clear=True)
+    assert float((half - 0.5 * a).abs().max()) <= 1e-6
+    # monotone in the object set: drawing only the first half of every sample is <= the full map
+    part = torch.empty_like(a)
+    draw_heatmap_batched(part, rb(c.tensor, (sizes // 2).to(DEV)), rb(r.tensor, (sizes // 2).to(DEV)), clear=True)
+    assert bool((part <= a).all())
+    # and drawing the rest on top of it in place reproduces the full map
+    rest_c = [t[n // 2:] for t, n in zip(cl, sizes.tolist())]
+    rest_r = [t[n // 2:] for t, n in zip(rl, sizes.tolist())]
+    rc, rs = wl.pad_ragged(rest_c)
+    rr, _ = wl.pad_ragged(rest_r)
+    draw_heatmap_batched(part, rb(rc.to(DEV), rs.to(DEV)), rb(rr.to(DEV), rs.to(DEV)))
+    assert torch.equal(part, a)
