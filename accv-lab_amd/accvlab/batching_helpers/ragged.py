@@ -184,7 +184,7 @@ class RaggedBatch:
     # ------------------------------------------------------------------ derived instances
     def as_self_with_cloned_data(self) -> "RaggedBatch":
         """Copy with a cloned data tensor; mask and sizes are shared."""
-        return RaggedBatch(self._tensor.clone(), self.mask, self.sample_sizes, self._non_uniform_dim)
+        return RaggedBatch(self._tensor.clone(), self._mask, self._sample_sizes, self._non_uniform_dim)
 
     def create_with_sample_sizes_like_self(self, tensor: torch.Tensor, non_uniform_dim: Optional[int] = None,
                                            device=None) -> "RaggedBatch":
@@ -207,7 +207,11 @@ class RaggedBatch:
             device = tensor.device
         else:
             tensor = tensor.to(device=device)
-        out = RaggedBatch(tensor, self.mask.to(device=device), self.sample_sizes.to(device=device), non_uniform_dim)
+        # share what has been materialised so far; a missing mask / size tensor stays lazy in the new instance too
+        # (the reference forces the mask here, ragged_batch.py:455-457: an extra fill kernel per derived batch)
+        mask = self._mask.to(device=device) if self._mask is not None else None
+        sizes = self._sample_sizes.to(device=device) if self._sample_sizes is not None else None
+        out = RaggedBatch(tensor, mask, sizes, non_uniform_dim)
         out._total_entries = self._total_entries
         return out
 
@@ -323,10 +327,10 @@ class RaggedBatch:
         return self.to_device(torch.device("cpu"))
 
     def to_dtype(self, dtype: torch.dtype) -> "RaggedBatch":
-        return RaggedBatch(self._tensor.to(dtype=dtype), self.mask, self.sample_sizes, self._non_uniform_dim)
+        return RaggedBatch(self._tensor.to(dtype=dtype), self._mask, self._sample_sizes, self._non_uniform_dim)
 
     def detach(self) -> "RaggedBatch":
-        return RaggedBatch(self._tensor.detach(), self.mask, self.sample_sizes, self._non_uniform_dim)
+        return RaggedBatch(self._tensor.detach(), self._mask, self._sample_sizes, self._non_uniform_dim)
 
     def to(self, *args, **kwargs) -> "RaggedBatch":
         """``tensor.to(*args, **kwargs)``; mask and sizes follow to the new device if it changed."""
@@ -376,7 +380,7 @@ class RaggedBatch:
             out = proc_step(self._tensor, self.mask, self.sample_sizes)
         else:
             raise ValueError(f"Function {proc_step} has {nargs} arguments, but only 1, 2, or 3 are supported.")
-        wrap = lambda t: RaggedBatch(t, self.mask, self.sample_sizes, self._non_uniform_dim)  # noqa: E731
+        wrap = lambda t: RaggedBatch(t, self._mask, self._sample_sizes, self._non_uniform_dim)  # noqa: E731
         return tuple(wrap(t) for t in out) if isinstance(out, tuple) else wrap(out)
 
     def set_tensor(self, tensor: torch.Tensor) -> None:
