@@ -75,13 +75,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; ACCV_BENCH_BACKEND=gloo lets several ranks share a GPU to REHEARSE the multi-rank control flow
+    # on a one-GPU box (the real runs use RCCL = backend "nccl")
+    backend = os.environ.get("ACCV_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
-        import torch.distributed as dist  # RCCL; used only for the barrier and the max-over-ranks of the time
+        import torch.distributed as dist  # used only for the barrier and the max-over-ranks of the time
 
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from accvlab.batching_helpers import combine_data
     from accvlab.draw_heatmap import draw_heatmap_batched
@@ -124,7 +131,7 @@ def main():
     wall_ms = (t1 - t0) * 1e3 / args.steps
     kern_ms = e0.elapsed_time(e1) / args.steps
     if dist is not None:
-        t = torch.tensor([wall_ms, kern_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([wall_ms, kern_ms], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_ms, kern_ms = float(t[0]), float(t[1])
 

@@ -366,3 +366,41 @@ def test_full_size_equivalences_and_scaling():
     rr, _ = wl.pad_ragged(rest_r)
     draw_heatmap_batched(part, rb(rc.to(DEV), rs.to(DEV)), rb(rr.to(DEV), rs.to(DEV)))
     assert torch.equal(part, a)
+
+
+def test_batched_op_is_graph_capturable():
+    """The batched entry point enqueues exactly one kernel, allocates nothing and never synchronises: it can be
+    captured into a hipGraph (torch.cuda.CUDAGraph) and replayed with updated inputs."""
+    _, draw_heatmap_batched = _dh()
+    B, H, W = 3, 128, 256
+    cl, rl = wl.heatmap_objects(B, H, W, 1, 20, "A", seed=11)
+    cpad, sizes = wl.pad_ragged(cl)
+    rpad, _ = wl.pad_ragged(rl)
+    c, r = rb(cpad.to(DEV), sizes.to(DEV)), rb(rpad.to(DEV), sizes.to(DEV))
+    hm = torch.zeros((B, H, W), device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        draw_heatmap_batched(hm, c, r, clear=True)       # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        draw_heatmap_batched(hm, c, r, clear=True)
+    ref = np.zeros((B, H, W), dtype=np.float32)
+    oracle.draw_heatmap_batched(ref, cpad.numpy(), rpad.numpy(), sizes.numpy(), clear=True)
+    hm.fill_(5.0)
+    graph.replay()
+    _close(hm, ref, "graph replay")
+    # new object data in the SAME buffers, replay again
+    cl2, rl2 = wl.heatmap_objects(B, H, W, 1, 20, "A", seed=12)
+    c2, s2 = wl.pad_ragged(cl2)
+    r2, _ = wl.pad_ragged(rl2)
+    n = min(c2.shape[1], cpad.shape[1])
+    s2 = s2.clamp(max=n)
+    c.tensor[:, :n].copy_(c2[:, :n].to(DEV))
+    r.tensor[:, :n].copy_(r2[:, :n].to(DEV))
+    c.sample_sizes.copy_(s2.to(DEV))
+    graph.replay()
+    ref2 = np.zeros((B, H, W), dtype=np.float32)
+    oracle.draw_heatmap_batched(ref2, c.tensor.cpu().numpy(), r.tensor.cpu().numpy(), s2.numpy(), clear=True)
+    _close(hm, ref2, "graph replay with new inputs")
