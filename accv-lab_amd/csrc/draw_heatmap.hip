@@ -72,6 +72,17 @@ struct Vec<1> {
 
 __device__ __forceinline__ float raw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// max that treats a quiet NaN as "no data" in ONE instruction.  fmaxf() has the same meaning, but hipcc puts a
+// canonicalising v_max_f32 x, x, x in front of every call whose operand it cannot prove to be a quiet value (the
+// loop-carried accumulator), i.e. 3 VALU ops per pixel instead of 2.  All masks in this file are the quiet NaN
+// 0x7fc00000 and products of a quiet NaN stay quiet, so the raw instruction is exact here.
+__device__ __forceinline__ float max_skip_nan(float acc, float v)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(acc), "v"(v));
+    return r;
+}
+
 template <int PX, int R, bool CLEAR, int SM, int WPG = kWavesPerGroup>
 __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
 {
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int c = 0; c < PX; ++c) acc[4 * q + i][c] = fmaxf(acc[4 * q + i][c], ex[c] * ey[i]);
+                    for (int c = 0; c < PX; ++c) acc[4 * q + i][c] = max_skip_nan(acc[4 * q + i][c], ex[c] * ey[i]);
             }
         }
         total_hits += nh;
@@ -373,10 +384,10 @@ __global__ __launch_bounds__(NW * 64) void splat_rows_kernel(const SplatParams p
                 for (int j = 0; j < 4; ++j) {
                     if (h4 + j < nh) {
                         const float4 ex4 = *reinterpret_cast<const float4*>(&s_ex[h4 + j][colq * 4]);
-                        acc[0] = fmaxf(acc[0], ex4.x * ey[j]);
-                        acc[1] = fmaxf(acc[1], ex4.y * ey[j]);
-                        acc[2] = fmaxf(acc[2], ex4.z * ey[j]);
-                        acc[3] = fmaxf(acc[3], ex4.w * ey[j]);
+                        acc[0] = max_skip_nan(acc[0], ex4.x * ey[j]);
+                        acc[1] = max_skip_nan(acc[1], ex4.y * ey[j]);
+                        acc[2] = max_skip_nan(acc[2], ex4.z * ey[j]);
+                        acc[3] = max_skip_nan(acc[3], ex4.w * ey[j]);
                     }
                 }
             }

@@ -26,10 +26,11 @@ def main():
     ap.add_argument("--knobs", default="hm_wpg=1,4;hm_nt=0,4",
                     help="knobs understood by libaccv_hip: hm_kernel=1|2, hm_nw=16|8, hm_wpg=1|4, hm_rows=8|16, hm_nt=0|1|2|4")
     ap.add_argument("--empty", action="store_true", help="no objects: isolates the store pattern")
+    ap.add_argument("--nmin", type=int, default=1, help="minimum objects per frame (128 = densest case)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     B, H, W = args.batch, 1080, 1920
-    cl, rl = wl.heatmap_objects(B, H, W, 1, 128, args.rule, seed=42)
+    cl, rl = wl.heatmap_objects(B, H, W, args.nmin, 128, args.rule, seed=42)
     cpad, sizes = wl.pad_ragged(cl)
     if args.empty:
         sizes = torch.zeros_like(sizes)
