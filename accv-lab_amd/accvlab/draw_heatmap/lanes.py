@@ -1,0 +1,88 @@
+"""Lane (polyline) rasteriser — the "lane_helpers polyline raster" of BASELINE.json config 3.
+
+EXTENSION: the reference ships no polyline rasteriser; its lane package only samples polylines
+(packages/lane_helpers/accvlab/lane_helpers/polyline/functions.py:27-111).  A lane is drawn here by composing the two
+reference operators that exist: sample every lane at ``num_samples`` arc-length-uniform positions (``interpolate`` with
+``relative=True``) and splat every sample as a Gaussian of a fixed radius (``draw_heatmap_batched``).  Three launches,
+no host synchronisation:
+
+    accv_polyline_sample  ->  accv_heatmap_targets_from_points_f32  ->  accv_draw_heatmap_batched_f32
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+
+from .. import _amd_native as _nat
+from ..lane_helpers.polyline import ops as _poly
+from .ops import _require, draw_heatmap_batched
+
+_cache: dict = {}
+
+
+def _cached(key, make):
+    t = _cache.get(key)
+    if t is None:
+        if len(_cache) > 64:
+            _cache.clear()
+        t = _cache[key] = make()
+    return t
+
+
+def sample_lane_targets(polylines: torch.Tensor, num_samples: int, radius: int, out_size_factor: float = 1.0, *,
+                        num_points: Optional[torch.Tensor] = None):
+    """``polylines`` f32 ``[B, L, P, 2]`` (x, y in source pixels; ``num_points`` int ``[B, L]`` = valid points per
+    lane, default all) -> ``(centers i32 [B, L*num_samples, 2], radii i32 [B, L*num_samples])`` at the heat-map stride
+    ``out_size_factor``: ``c = int(sample / stride)``.  Samples of empty lanes get radius -1 (never drawn)."""
+    _require(isinstance(polylines, torch.Tensor) and polylines.is_cuda, "polylines must be a CUDA tensor")
+    _require(polylines.dim() == 4 and polylines.size(3) == 2, "polylines must be of shape [batch, lanes, points, 2]")
+    _require(polylines.dtype == torch.float32, f"polylines: expected float32 but found {polylines.dtype}")
+    _require(num_samples >= 1, "num_samples must be >= 1")
+    b, l, p, _ = polylines.shape
+    dev = polylines.device
+    pts = polylines.contiguous().view(b * l, p, 2)
+    counts = None
+    if num_points is not None:
+        _require(num_points.shape == (b, l), "num_points must be of shape [batch, lanes]")
+        _require(num_points.device == dev, "num_points must be on the same device as polylines")
+        _poly._check_sizes(num_points.reshape(-1), p, "num_points")
+        counts = num_points.contiguous().view(b * l)
+    centers = torch.empty((b, l * num_samples, 2), dtype=torch.int32, device=dev)
+    radii = torch.empty((b, l * num_samples), dtype=torch.int32, device=dev)
+    if b * l == 0:
+        return centers, radii
+    # arc-length fractions 0..1, one row per lane (a cached constant: no per-call kernel)
+    frac = _cached(("frac", b * l, num_samples, dev), lambda: torch.linspace(
+        0.0, 1.0, num_samples, device=dev).unsqueeze(0).expand(b * l, num_samples).contiguous()
+        if num_samples > 1 else torch.zeros((b * l, 1), device=dev))
+    samples = _poly._gpu(pts, frac, counts, None, True, True, False)[0]
+    with torch.cuda.device(dev):
+        _nat.check(_nat.lib().accv_heatmap_targets_from_points_f32(
+            samples.data_ptr(), b * l * num_samples, float(out_size_factor), int(radius), centers.data_ptr(),
+            radii.data_ptr(), _nat.stream_ptr(dev)), "sample_lane_targets")
+    return centers, radii
+
+
+def draw_polylines_batched(heatmap: torch.Tensor, polylines: torch.Tensor, num_samples: int, radius: int,
+                           out_size_factor: float = 1.0, diameter_to_sigma_factor: float = 6.0, k_scale: float = 1.0,
+                           *, num_points: Optional[torch.Tensor] = None, num_lanes: Optional[torch.Tensor] = None,
+                           clear: bool = False) -> None:
+    """Draw ``polylines`` f32 ``[B, L, P, 2]`` into ``heatmap`` f32 ``[B, H, W]`` (in place, element-wise max; with
+    ``clear=True`` fused zero-fill + draw) as chains of Gaussians of ``radius``.
+
+    ``num_points`` int ``[B, L]``: valid points per lane; ``num_lanes`` int ``[B]``: only the first ``num_lanes[b]``
+    lanes of a frame are drawn (both default to "all").  Choose ``num_samples`` so that the sample spacing
+    (lane length / stride / (num_samples-1)) stays below ``radius`` for a gap-free line."""
+    centers, radii = sample_lane_targets(polylines, num_samples, radius, out_size_factor, num_points=num_points)
+    b, l = polylines.shape[:2]
+    if num_lanes is None:
+        sizes = _cached(("full", b, l * num_samples, heatmap.device),
+                        lambda: torch.full((b,), l * num_samples, dtype=torch.int32, device=heatmap.device))
+    else:
+        _require(num_lanes.shape == (b,), "num_lanes must be of shape [batch]")
+        sizes = num_lanes.clamp(0, l) * num_samples
+    draw_heatmap_batched(heatmap, SimpleNamespace(tensor=centers, sample_sizes=sizes),
+                         SimpleNamespace(tensor=radii, sample_sizes=sizes), diameter_to_sigma_factor, k_scale,
+                         clear=clear)

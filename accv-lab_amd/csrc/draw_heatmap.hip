@@ -33,10 +33,9 @@ struct SplatParams {
     float* hm;
     const int32_t* centers;
     const int32_t* radii;
-    const int32_t* labels;     // class-wise batched only
+    const int32_t* labels;     // class-wise batched: labels; otherwise any readable int32 array shaped like radii
     const void* counts;        // batched: i32[B] or i64[B]
-    const int32_t* plane_off;  // flat: [P+1] offsets into obj_list
-    const int32_t* obj_list;   // flat: object ids grouped by plane
+    const int32_t* plane_off;  // flat: [P+1] offsets into centers/radii (which are then the plane-sorted copies)
     int H, W;
     int n_max;      // batched: padded objects per sample
     int n_classes;  // class-wise: C, else 0
@@ -47,15 +46,13 @@ struct SplatParams {
     int grid3d;           // tile index comes from a 3-D grid instead of a linear block index
 };
 
-struct __attribute__((aligned(16))) HitX {  // column side of a hit, read as one ds_read_b128 broadcast
-    int x;
-    float c2;  // log2(e) / var
-    int x0, x1;
-};
-struct __attribute__((aligned(16))) HitY {
-    int y;
-    float c2;
-    int y0, y1;
+// one culled hit, read back as a single ds_read_b128 broadcast.  The clipped box is stored relative to the tile and
+// clamped to it (each bound fits a byte: tiles are at most 128 x 32), so a wave needs 1 KB for the list instead of 2
+// and 5 KB of LDS in total -> 32 single-wave workgroups (8 waves per SIMD) fit a CU's 160 KB
+struct __attribute__((aligned(16))) Hit {
+    int x, y;
+    float c2;      // log2(e) / var
+    unsigned box;  // xlo | xhi << 8 | ylo << 16 | yhi << 24 : columns [xlo,xhi), rows [ylo,yhi) of the tile
 };
 
 template <int PX>
@@ -91,8 +88,7 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
     constexpr int TH = 2 * R;    // the two half-waves take R rows each
     static_assert(R % 4 == 0, "row registers are fetched four at a time");
 
-    __shared__ HitX s_hx[kWavesPerGroup][kCand];
-    __shared__ HitY s_hy[kWavesPerGroup][kCand];
+    __shared__ Hit s_hit[kWavesPerGroup][kCand];
     __shared__ __attribute__((aligned(16))) float s_ey[kWavesPerGroup][kCand][TH];
 
     const int lane = threadIdx.x & 63;
@@ -117,11 +113,10 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
     const int tx0 = tx * TW, ty0 = ty * TH;
     const int tx1 = min(tx0 + TW, p.W), ty1 = min(ty0 + TH, p.H);
 
-    // which objects feed this plane
+    // which objects feed this plane: objects [obj_base, obj_base + n) of centers/radii(/labels)
     long long obj_base;
     int n, cls = -1;
-    const bool flat = p.obj_list != nullptr;
-    if (flat) {
+    if (p.plane_off) {  // flat API: the binning pre-pass left plane-sorted copies of the objects
         const int o0 = p.plane_off[plane];
         obj_base = o0;
         n = p.plane_off[plane + 1] - o0;
@@ -148,24 +143,26 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
 
     int total_hits = 0;
 
+    // One candidate per lane and round, fetched with branch-free loads (index clamped to the last object, result
+    // masked).  The cull is VALU-bound for long object lists (lane rasters walk 10^3 candidates per tile), so the test
+    // every lane runs is a cheap CONSERVATIVE one in 32-bit: coordinates clamped to +-2^29 and the radius to 2^30
+    // cannot overflow and never miss a real hit while H, W <= 2^29 (host-checked); the exact clipped box of the
+    // reference (64-bit) is only computed for lanes that hit, and an empty exact box simply masks every pixel.
+    const int2* __restrict__ centers2 = reinterpret_cast<const int2*>(p.centers) + obj_base;
+    const int32_t* __restrict__ radii = p.radii + obj_base;
+    const int32_t* __restrict__ labels = p.labels + obj_base;
+    constexpr int kClampXY = 1 << 29, kClampR = 1 << 30;
+
     for (int base = 0; base < n; base += kCand) {
-        // ---- cull: one candidate per lane, ballot, popcount-prefix compaction into LDS
-        const int ci = base + lane;
-        bool hit = false;
-        int x = 0, y = 0, r = 0;
-        if (ci < n) {
-            const long long o = flat ? (long long)p.obj_list[obj_base + ci] : obj_base + ci;
-            const int2 cxy = reinterpret_cast<const int2*>(p.centers)[o];
-            x = cxy.x;
-            y = cxy.y;
-            r = p.radii[o];
-            hit = true;
-            if (cls >= 0) hit = p.labels[o] == cls;
-        }
-        // clipped box, exactly the reference's left/right/top/bottom (cuh:64-67, 92-95), in 64-bit
-        const long long x0 = (long long)x - min(x, r), x1 = (long long)x + min((long long)p.W - x, (long long)r + 1);
-        const long long y0 = (long long)y - min(y, r), y1 = (long long)y + min((long long)p.H - y, (long long)r + 1);
-        hit = hit && x1 > x0 && y1 > y0 && x0 < tx1 && x1 > tx0 && y0 < ty1 && y1 > ty0;
+        // ---- cull: ballot, popcount-prefix compaction into LDS
+        const int cc = min(base + lane, n - 1);
+        const int2 cxy = centers2[cc];
+        const int x = cxy.x, y = cxy.y, r = radii[cc];
+        const int label = labels[cc];
+        const int xc = min(max(x, -kClampXY), kClampXY), yc = min(max(y, -kClampXY), kClampXY);
+        const int rc = min(r, kClampR);
+        const bool hit = (base + lane < n) && (cls < 0 || label == cls) && r >= 0 && xc - rc < tx1 && xc + rc >= tx0 &&
+                         yc - rc < ty1 && yc + rc >= ty0;
 
         const unsigned long long m = __ballot(hit);
         const int nh = __popcll(m);
@@ -196,8 +193,16 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
             const int pos = __popcll(m & ((1ull << lane) - 1ull));
             const float sigma = (float)(2 * r + 1) / p.factor;
             const float c2 = kLog2e / (2.0f * sigma * sigma);
-            s_hx[wave][pos] = HitX{x, c2, (int)x0, (int)x1};
-            s_hy[wave][pos] = HitY{y, c2, (int)y0, (int)y1};
+            // clipped box, exactly the reference's left/right/top/bottom (cuh:64-67, 92-95), in 64-bit, then relative
+            // to the tile and clamped to it
+            const long long x0 = (long long)x - min(x, r), x1 = (long long)x + min((long long)p.W - x, (long long)r + 1);
+            const long long y0 = (long long)y - min(y, r), y1 = (long long)y + min((long long)p.H - y, (long long)r + 1);
+            const long long xlo = max(x0, (long long)tx0) - tx0, xhi = min(x1, (long long)tx1) - tx0;
+            const long long ylo = max(y0, (long long)ty0) - ty0, yhi = min(y1, (long long)ty1) - ty0;
+            unsigned box = 0;  // empty: only possible for coordinates beyond the clamps above
+            if (xhi > xlo && yhi > ylo)
+                box = (unsigned)xlo | ((unsigned)xhi << 8) | ((unsigned)ylo << 16) | ((unsigned)yhi << 24);
+            s_hit[wave][pos] = Hit{x, y, c2, box};
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -205,25 +210,26 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
         // ---- row-factor table: ey[h][row] = k * exp(-dy^2/var), NaN outside the clipped rows
         for (int t = lane; t < nh * TH; t += 64) {
             const int h = t / TH, rr = t % TH;
-            const HitY hy = s_hy[wave][h];
-            const int row = ty0 + rr;
-            const float d = (float)(row - hy.y);
+            const Hit hy = s_hit[wave][h];
+            const float d = (float)(ty0 + rr - hy.y);
             const float v = p.k * raw_exp2(-(d * d) * hy.c2);
-            s_ey[wave][h][rr] = (row >= hy.y0 && row < hy.y1) ? v : __builtin_nanf("");
+            const unsigned ylo = (hy.box >> 16) & 255u, yhi = hy.box >> 24;
+            s_ey[wave][h][rr] = ((unsigned)rr >= ylo && (unsigned)rr < yhi) ? v : __builtin_nanf("");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // ---- accumulate: per hit PX column factors in registers, row factors from LDS
+        const unsigned colr0 = (unsigned)(lane & 31) * PX;  // first column of this lane, tile relative
         for (int h = 0; h < nh; ++h) {
-            const HitX hx = s_hx[wave][h];
+            const Hit hx = s_hit[wave][h];
+            const unsigned xlo = hx.box & 255u, xhi = (hx.box >> 8) & 255u;
             float ex[PX];
 #pragma unroll
             for (int c = 0; c < PX; ++c) {
-                const int col = col0 + c;
-                const float d = (float)(col - hx.x);
+                const float d = (float)(col0 + c - hx.x);
                 const float e = raw_exp2(-(d * d) * hx.c2);
-                ex[c] = (col >= hx.x0 && col < hx.x1) ? e : __builtin_nanf("");
+                ex[c] = (colr0 + c >= xlo && colr0 + c < xhi) ? e : __builtin_nanf("");
             }
 #pragma unroll
             for (int q = 0; q < R / 4; ++q) {
@@ -269,179 +275,6 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
     }
 }
 
-// ---------------------------------------------------------------- v2: one store per wave ("row-pair waves")
-// Store-pattern microbenchmarks (profiles/r01_fill_patterns3_*.log) show that waves issuing ONE 16-byte-per-lane
-// store reach 6.5-7.3 TB/s while any wave with >= 2 stores plateaus ~15-20 % lower.  So here a WORKGROUP of NW waves
-// owns a 128 x (2*NW) tile: wave 0 culls (ballot compaction, as above), all threads build LDS tables
-//   s_ex[hit][128 columns] = exp2(-dx^2 c)      (NaN outside the clipped columns)
-//   s_ey[row][hit]         = k exp2(-dy^2 c)    (NaN outside the clipped rows)
-// and each wave then owns rows (2w, 2w+1): per hit one ds_read_b128 of column factors, one broadcast row factor,
-// 4 multiplies + 4 max — and exactly ONE write-through store at the end.
-template <int NW, bool CLEAR, int SM>
-__global__ __launch_bounds__(NW * 64) void splat_rows_kernel(const SplatParams p)
-{
-    constexpr int TW = 128, TH = 2 * NW;
-    __shared__ HitX s_hx[kCand];
-    __shared__ HitY s_hy[kCand];
-    __shared__ __attribute__((aligned(16))) float s_ex[kCand][TW];
-    __shared__ __attribute__((aligned(16))) float s_ey[TH][kCand];
-    __shared__ int s_nh;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // 3-D grid (x = column tile, y = row tile, z = plane): no divisions in the per-wave prologue
-    const int tx = blockIdx.x, ty = blockIdx.y;
-    const unsigned plane = blockIdx.z;
-    const int tx0 = tx * TW, ty0 = ty * TH;
-    const int tx1 = min(tx0 + TW, p.W), ty1 = min(ty0 + TH, p.H);
-
-    unsigned obj_base;
-    int n, cls = -1;
-    const bool flat = p.obj_list != nullptr;
-    if (flat) {
-        const int o0 = p.plane_off[plane];
-        obj_base = (unsigned)o0;
-        n = p.plane_off[plane + 1] - o0;
-    } else {
-        unsigned s = plane;
-        if (p.n_classes > 0) {
-            s = plane / (unsigned)p.n_classes;
-            cls = (int)(plane - s * (unsigned)p.n_classes);
-        }
-        const long long cnt = p.counts_i64 ? ((const long long*)p.counts)[s] : (long long)((const int*)p.counts)[s];
-        n = (int)max(0ll, min(cnt, (long long)p.n_max));
-        obj_base = s * (unsigned)p.n_max;
-    }
-
-    const int row = ty0 + 2 * wave + (lane >> 5);
-    const int colq = (lane & 31);  // float4 column group inside the tile
-    const int col0 = tx0 + colq * 4;
-    const float nanv = __builtin_nanf("");
-    float acc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = CLEAR ? 0.0f : nanv;
-    int total_hits = 0;
-
-    for (int base = 0; base < n; base += kCand) {
-        if (wave == 0) {  // cull: one candidate per lane of wave 0
-            const int ci = base + lane;
-            bool hit = false;
-            int x = 0, y = 0, r = 0;
-            if (ci < n) {
-                const unsigned o = flat ? (unsigned)p.obj_list[obj_base + ci] : obj_base + ci;
-                const int2 cxy = reinterpret_cast<const int2*>(p.centers)[o];
-                x = cxy.x;
-                y = cxy.y;
-                r = p.radii[o];
-                hit = true;
-                if (cls >= 0) hit = p.labels[o] == cls;
-            }
-            const long long x0 = (long long)x - min(x, r), x1 = (long long)x + min((long long)p.W - x, (long long)r + 1);
-            const long long y0 = (long long)y - min(y, r), y1 = (long long)y + min((long long)p.H - y, (long long)r + 1);
-            hit = hit && x1 > x0 && y1 > y0 && x0 < tx1 && x1 > tx0 && y0 < ty1 && y1 > ty0;
-            const unsigned long long m = __ballot(hit);
-            if (hit) {
-                const int pos = __popcll(m & ((1ull << lane) - 1ull));
-                const float sigma = (float)(2 * r + 1) / p.factor;
-                const float c2 = kLog2e / (2.0f * sigma * sigma);
-                s_hx[pos] = HitX{x, c2, (int)x0, (int)x1};
-                s_hy[pos] = HitY{y, c2, (int)y0, (int)y1};
-            }
-            if (lane == 0) s_nh = __popcll(m);
-        }
-        __syncthreads();
-        const int nh = s_nh;
-        if (nh > 0) {
-            const int nh4 = (nh + 3) & ~3;
-            // column factors: consecutive threads -> consecutive columns of one hit
-            for (int i = tid; i < nh * TW; i += NW * 64) {
-                const int h = i / TW, c = i % TW;
-                const HitX hx = s_hx[h];
-                const int col = tx0 + c;
-                const float d = (float)(col - hx.x);
-                const float e = raw_exp2(-(d * d) * hx.c2);
-                s_ex[h][c] = (col >= hx.x0 && col < hx.x1) ? e : nanv;
-            }
-            // row factors, [row][hit] so that a wave fetches four hits of its row with one ds_read_b128
-            for (int i = tid; i < TH * nh4; i += NW * 64) {
-                const int rr = i / nh4, h = i % nh4;
-                float v = nanv;
-                if (h < nh) {
-                    const HitY hy = s_hy[h];
-                    const int rw = ty0 + rr;
-                    const float d = (float)(rw - hy.y);
-                    if (rw >= hy.y0 && rw < hy.y1) v = p.k * raw_exp2(-(d * d) * hy.c2);
-                }
-                s_ey[rr][h] = v;
-            }
-            __syncthreads();
-            const int myrow = 2 * wave + (lane >> 5);
-            for (int h4 = 0; h4 < nh4; h4 += 4) {
-                const float4 ey4 = *reinterpret_cast<const float4*>(&s_ey[myrow][h4]);
-                const float ey[4] = {ey4.x, ey4.y, ey4.z, ey4.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (h4 + j < nh) {
-                        const float4 ex4 = *reinterpret_cast<const float4*>(&s_ex[h4 + j][colq * 4]);
-                        acc[0] = max_skip_nan(acc[0], ex4.x * ey[j]);
-                        acc[1] = max_skip_nan(acc[1], ex4.y * ey[j]);
-                        acc[2] = max_skip_nan(acc[2], ex4.z * ey[j]);
-                        acc[3] = max_skip_nan(acc[3], ex4.w * ey[j]);
-                    }
-                }
-            }
-            total_hits += nh;
-        }
-        __syncthreads();  // tables and s_nh are reused by the next round
-    }
-
-    if (!CLEAR && total_hits == 0) return;
-    if (row >= p.H || col0 >= p.W) return;
-    float* plane_ptr = p.hm + (size_t)plane * (size_t)p.H * (size_t)p.W;
-    vfloat4* dst = reinterpret_cast<vfloat4*>(plane_ptr + (size_t)row * p.W + col0);
-    vfloat4 out;
-    if constexpr (!CLEAR) {
-        const vfloat4 old = *dst;
-        out = vfloat4{fmaxf(old.x, acc[0]), fmaxf(old.y, acc[1]), fmaxf(old.z, acc[2]), fmaxf(old.w, acc[3])};
-    } else {
-        out = vfloat4{acc[0], acc[1], acc[2], acc[3]};
-    }
-    if constexpr (SM >= 2) {
-        constexpr int aux = SM == 2 ? 16 : 18;  // sc1 | sc1+nt
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(out, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, aux);
-    } else if constexpr (SM == 1) {
-        __builtin_nontemporal_store(out, dst);
-    } else {
-        *dst = out;
-    }
-}
-
-template <int NW>
-int launch_splat_rows(SplatParams p, long long planes, bool clear, int sm, hipStream_t stream)
-{
-    p.tiles_x = (p.W + 127) / 128;
-    p.tiles_y = (p.H + 2 * NW - 1) / (2 * NW);
-    p.n_tiles = planes * p.tiles_x * p.tiles_y;
-    if (p.n_tiles == 0) return ACCV_OK;
-    const dim3 grid((unsigned)p.tiles_x, (unsigned)p.tiles_y, (unsigned)planes), block(NW * 64);
-#define ACCV_LAUNCH_ROWS(SMV)                                                                            \
-    do {                                                                                                 \
-        if (clear)                                                                                       \
-            hipLaunchKernelGGL((splat_rows_kernel<NW, true, SMV>), grid, block, 0, stream, p);           \
-        else                                                                                             \
-            hipLaunchKernelGGL((splat_rows_kernel<NW, false, SMV>), grid, block, 0, stream, p);          \
-    } while (0)
-    switch (sm) {
-        case 2: ACCV_LAUNCH_ROWS(2); break;
-        case 4: ACCV_LAUNCH_ROWS(4); break;
-        default: ACCV_LAUNCH_ROWS(0); break;
-    }
-#undef ACCV_LAUNCH_ROWS
-    return accv::check_launch("draw_heatmap row-pair splat kernel");
-}
-
 // ---------------------------------------------------------------- target-prep front end
 // centres/boxes (float, source-image pixels) -> integer centre + radius at an output stride; one fused kernel for
 // the ~8 element-wise torch ops of the reference helper (packages/draw_heatmap/tests/_test_helpers.py:20-28):
@@ -459,6 +292,22 @@ __global__ __launch_bounds__(256) void targets_from_boxes_kernel(const float2* _
         if (r < 1) r = 1;
         out_radii[i] = r;
         out_centers[i] = make_int2((int)__fdiv_rn(c.x, stride), (int)__fdiv_rn(c.y, stride));
+    }
+}
+
+// sampled polyline points (float, source pixels) -> splat targets of a constant radius at an output stride:
+//   c = int(p / stride) (same rule as above); a NaN point (sample of an empty polyline,
+//   packages/lane_helpers/ext_impl/polyline/include/polyline_kernels.cuh:216-245) gets radius -1 = never drawn
+__global__ __launch_bounds__(256) void targets_from_points_kernel(const float2* __restrict__ points, long long n,
+                                                                  float stride, int radius,
+                                                                  int2* __restrict__ out_centers,
+                                                                  int* __restrict__ out_radii)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 c = points[i];
+        const bool bad = (c.x != c.x) || (c.y != c.y);
+        out_radii[i] = bad ? -1 : radius;
+        out_centers[i] = bad ? make_int2(0, 0) : make_int2((int)__fdiv_rn(c.x, stride), (int)__fdiv_rn(c.y, stride));
     }
 }
 
@@ -498,12 +347,20 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int* __restrict__ cnt, i
     if (t == 1023) off[planes] = s_part[1023];
 }
 
+// scatters every object into its plane's segment: the splat kernel then reads plane-sorted COPIES (centres, radii)
+// with unit stride instead of chasing an index list
 __global__ void bin_fill_kernel(const int32_t* __restrict__ idx, int n, int planes, const int* __restrict__ off,
-                                int* __restrict__ cursor, int* __restrict__ list)
+                                int* __restrict__ cursor, const int2* __restrict__ centers,
+                                const int32_t* __restrict__ radii, int2* __restrict__ sorted_centers,
+                                int32_t* __restrict__ sorted_radii)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int pl = idx[i];
-        if (pl >= 0 && pl < planes) list[off[pl] + atomicAdd(&cursor[pl], 1)] = i;
+        if (pl >= 0 && pl < planes) {
+            const int dst = off[pl] + atomicAdd(&cursor[pl], 1);
+            sorted_centers[dst] = centers[i];
+            sorted_radii[dst] = radii[i];
+        }
     }
 }
 
@@ -539,9 +396,9 @@ int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_
 #define ACCV_LAUNCH_SM(SMV)                                                                              \
     do {                                                                                                 \
         if (clear)                                                                                       \
-            hipLaunchKernelGGL((splat_kernel<PX, R, true, SMV, WPG>), grid, block, 0, stream, p);        \
+            hipLaunchKernelGGL((splat_kernel<PX, R, true, SMV, WPG>), grid, block, 0, stream, p);    \
         else                                                                                             \
-            hipLaunchKernelGGL((splat_kernel<PX, R, false, SMV, WPG>), grid, block, 0, stream, p);       \
+            hipLaunchKernelGGL((splat_kernel<PX, R, false, SMV, WPG>), grid, block, 0, stream, p);   \
     } while (0)
     if constexpr (PX == 4) {
         switch (sm) {  // store mode: 0 plain, 1 non-temporal, 2 write-through (sc1), 4 write-through non-temporal
@@ -557,7 +414,7 @@ int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_
     return accv::check_launch("draw_heatmap splat kernel");
 }
 
-int dispatch_splat(const SplatParams& p, long long planes, bool clear, hipStream_t stream)
+int dispatch_splat(SplatParams p, long long planes, bool clear, hipStream_t stream)
 {
     const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.hm) & 15u) == 0);
     // store policy: outputs far larger than L2 + Infinity Cache stream straight to HBM with write-through,
@@ -569,14 +426,7 @@ int dispatch_splat(const SplatParams& p, long long planes, bool clear, hipStream
     if (nt < 0) nt = (total_bytes > ((size_t)128 << 20) && plane_fits_rsrc) ? 4 : 0;
     if (nt >= 2 && !plane_fits_rsrc) nt = 0;
     // tuning knobs exist for in-process A/B runs (scripts/h1_variants.py); the defaults are the shipped configuration
-    const int kernel = accv::tune_get("hm_kernel", 1);
-    // the row-pair kernel addresses objects/planes with 32-bit math and a 3-D grid
-    const bool fits32 = planes <= 65535 && (long long)planes * std::max(p.n_max, 1) < (1ll << 31) &&
-                        (p.H + 7) / 8 <= 65535;
-    if (vec4 && kernel == 2 && fits32) {
-        if (accv::tune_get("hm_nw", 16) == 8) return launch_splat_rows<8>(p, planes, clear, nt, stream);
-        return launch_splat_rows<16>(p, planes, clear, nt, stream);
-    }
+    if (!p.labels) p.labels = p.radii;  // branch-free candidate loads: always a readable array (ignored when cls < 0)
     if (!vec4) return launch_splat<1, 8>(p, planes, clear, 0, stream);
     const int wpg = accv::tune_get("hm_wpg", kWavesPerGroup);
     if (accv::tune_get("hm_rows", 8) == 16) return launch_splat<4, 16>(p, planes, clear, nt, stream);
@@ -587,6 +437,8 @@ int dispatch_splat(const SplatParams& p, long long planes, bool clear, hipStream
 int check_common(const void* hm, int h, int w, float factor, const char* who)
 {
     if (h < 0 || w < 0) return accv::fail(ACCV_EINVAL, "%s: negative heatmap extent %dx%d", who, h, w);
+    if (h > (1 << 29) || w > (1 << 29))
+        return accv::fail(ACCV_EINVAL, "%s: heatmap extent %dx%d exceeds 2^29 per dimension", who, h, w);
     (void)hm;
     (void)factor;
     return ACCV_OK;
@@ -599,8 +451,9 @@ extern "C" {
 size_t accv_draw_heatmap_flat_workspace_bytes(int num_planes, int num_objects)
 {
     if (num_planes < 0 || num_objects < 0) return 0;
+    // bin counters [P] | plane offsets [P+1] | plane-sorted centres int2[N] | plane-sorted radii [N]
     return accv::align_up((size_t)num_planes * 4, 16) + accv::align_up(((size_t)num_planes + 1) * 4, 16) +
-           accv::align_up((size_t)num_objects * 4, 16) + 16;
+           accv::align_up((size_t)num_objects * 8, 16) + accv::align_up((size_t)num_objects * 4, 16) + 16;
 }
 
 int accv_draw_heatmap_flat_f32(float* heatmaps, int num_planes, int height, int width, const int32_t* centers,
@@ -611,6 +464,7 @@ int accv_draw_heatmap_flat_f32(float* heatmaps, int num_planes, int height, int 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = check_common(heatmaps, height, width, diameter_to_sigma_factor, "draw_heatmap")) return rc;
     if (num_planes < 0 || num_objects < 0) return accv::fail(ACCV_EINVAL, "draw_heatmap: negative count");
+    if (num_objects > (1 << 30)) return accv::fail(ACCV_EINVAL, "draw_heatmap: more than 2^30 objects");
     const bool clear = (flags & ACCV_HM_CLEAR) != 0;
     if (num_planes == 0 || height == 0 || width == 0) return ACCV_OK;
     if (!heatmaps) return accv::fail(ACCV_EINVAL, "draw_heatmap: heatmap pointer is null");
@@ -625,7 +479,9 @@ int accv_draw_heatmap_flat_f32(float* heatmaps, int num_planes, int height, int 
     char* ws = static_cast<char*>(workspace);
     int* cnt = reinterpret_cast<int*>(ws);
     int* off = reinterpret_cast<int*>(ws + accv::align_up((size_t)num_planes * 4, 16));
-    int* list = reinterpret_cast<int*>(reinterpret_cast<char*>(off) + accv::align_up(((size_t)num_planes + 1) * 4, 16));
+    char* sc_raw = reinterpret_cast<char*>(off) + accv::align_up(((size_t)num_planes + 1) * 4, 16);
+    int2* sorted_centers = reinterpret_cast<int2*>(sc_raw);
+    int32_t* sorted_radii = reinterpret_cast<int32_t*>(sc_raw + accv::align_up((size_t)num_objects * 8, 16));
 
     if (hipMemsetAsync(cnt, 0, (size_t)num_planes * 4, stream) != hipSuccess)
         return accv::fail(ACCV_ELAUNCH, "draw_heatmap: memset of the bin counters failed");
@@ -633,15 +489,15 @@ int accv_draw_heatmap_flat_f32(float* heatmaps, int num_planes, int height, int 
     if (num_objects > 0) hipLaunchKernelGGL(bin_count_kernel, dim3(nb), dim3(256), 0, stream, heatmap_idxes, num_objects, num_planes, cnt);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, off, num_planes);
     if (num_objects > 0)
-        hipLaunchKernelGGL(bin_fill_kernel, dim3(nb), dim3(256), 0, stream, heatmap_idxes, num_objects, num_planes, off, cnt, list);
+        hipLaunchKernelGGL(bin_fill_kernel, dim3(nb), dim3(256), 0, stream, heatmap_idxes, num_objects, num_planes, off, cnt,
+                           reinterpret_cast<const int2*>(centers), radii, sorted_centers, sorted_radii);
     if (int rc = accv::check_launch("draw_heatmap binning")) return rc;
 
     SplatParams p{};
     p.hm = heatmaps;
-    p.centers = centers;
-    p.radii = radii;
+    p.centers = reinterpret_cast<const int32_t*>(sorted_centers);
+    p.radii = sorted_radii;
     p.plane_off = off;
-    p.obj_list = list;
     p.H = height;
     p.W = width;
     p.factor = diameter_to_sigma_factor;
@@ -658,6 +514,8 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
     if (int rc = check_common(heatmap, height, width, diameter_to_sigma_factor, "draw_heatmap_batched")) return rc;
     if (batch < 0 || max_num_targets < 0 || num_classes < 0)
         return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: negative count");
+    if (max_num_targets > (1 << 30))
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: more than 2^30 objects per sample");
     if ((num_classes > 0) != (labels != nullptr))
         return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: labels and num_classes must be given together");
     if (batch == 0 || height == 0 || width == 0) return ACCV_OK;
@@ -701,6 +559,22 @@ int accv_heatmap_targets_from_boxes_f32(const float* centers_xy, const float* bo
                        reinterpret_cast<const float2*>(centers_xy), reinterpret_cast<const float4*>(boxes_xyxy),
                        num_objects, stride, reinterpret_cast<int2*>(out_centers), out_radii);
     return accv::check_launch("targets_from_boxes");
+}
+
+int accv_heatmap_targets_from_points_f32(const float* points_xy, long long num_points, float stride, int radius,
+                                         int32_t* out_centers, int32_t* out_radii, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (num_points < 0) return accv::fail(ACCV_EINVAL, "targets_from_points: negative count");
+    if (num_points == 0) return ACCV_OK;
+    if (!points_xy || !out_centers || !out_radii) return accv::fail(ACCV_EINVAL, "targets_from_points: null pointer");
+    if ((reinterpret_cast<uintptr_t>(points_xy) & 7u) || (reinterpret_cast<uintptr_t>(out_centers) & 7u))
+        return accv::fail(ACCV_EINVAL, "targets_from_points: points and centres need 8-byte alignment");
+    const unsigned grid = (unsigned)std::min<long long>((num_points + 255) / 256, 4096);
+    hipLaunchKernelGGL(targets_from_points_kernel, dim3(grid), dim3(256), 0, stream,
+                       reinterpret_cast<const float2*>(points_xy), num_points, stride, radius,
+                       reinterpret_cast<int2*>(out_centers), out_radii);
+    return accv::check_launch("targets_from_points");
 }
 
 int accv_fill_f32(float* dst, size_t count, float value, void* stream_)

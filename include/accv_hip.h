@@ -68,6 +68,13 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
 int accv_heatmap_targets_from_boxes_f32(const float* centers_xy, const float* boxes_xyxy, long long num_objects,
                                         float stride, int32_t* out_centers, int32_t* out_radii, void* stream);
 
+/* Lane front end (the "polyline raster" of BASELINE config 3): sampled polyline points f32[n,2] (x,y) in
+ * source pixels (output of accv_polyline_sample) -> int32 centres [n,2] = int(p / stride) and radii [n] = `radius`;
+ * NaN points (samples of empty polylines, polyline_kernels.cuh:216-245) get radius -1, which the splat never draws.
+ * The reference has no rasteriser for polylines; this feeds its sampler's output to accv_draw_heatmap_batched_f32. */
+int accv_heatmap_targets_from_points_f32(const float* points_xy, long long num_points, float stride, int radius,
+                                         int32_t* out_centers, int32_t* out_radii, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ H2
  * Ragged-batch kernels (batching_helpers).  Shapes are given after flattening all batch dimensions to
  * `batch` and all trailing data dimensions to `row_bytes` (= elements per index * element size): the

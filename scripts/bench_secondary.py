@@ -38,6 +38,18 @@ def _timeit(fn, warm, iters, sync=None):
     return (time.perf_counter() - t0) / iters
 
 
+def _graph_time(fn, warm=20, iters=500):
+    """ms per replay of `fn` captured into one hipGraph (GPU-side cost without the python/launch overhead)."""
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return _timeit(g.replay, warm, iters, torch.cuda.synchronize)
+
+
 def c0():
     from accvlab.batching_helpers import RaggedBatch, combine_data
 
@@ -147,9 +159,36 @@ def c3():
 
     t = _timeit(step, 50, 500, torch.cuda.synchronize)
     nbytes = sum(hm.numel() * 4 for hm, _, _ in scales)
+    tg = _graph_time(step)
     print(json.dumps({"config": "C3", "metric": "multi-scale heat-maps strides 4/8/16 of 3840x2160, batch 32",
                       "ms_per_batch": t * 1e3, "frames_per_s": B / t, "GBps": nbytes / t / 1e9,
-                      "bytes_per_frame": nbytes // B}))
+                      "bytes_per_frame": nbytes // B, "hipgraph_ms_per_batch": tg * 1e3,
+                      "hipgraph_frames_per_s": B / tg, "hipgraph_GBps": nbytes / tg / 1e9}))
+
+    # + lane raster: 8 lanes x 24 points per frame in source pixels, sampled at 256/128/64 arc-length positions (sample
+    # spacing ~ the splat radius at every scale) and splatted with radius 2 into one lane map per scale
+    # (sampler -> int targets -> fused clear+draw: 3 launches per scale)
+    from accvlab.draw_heatmap import draw_polylines_batched
+
+    L, P = 8, 24
+    x0 = torch.rand(B, L, 1, generator=g) * SW
+    t_ = torch.linspace(0, 1, P).view(1, 1, P)
+    xs = x0 + (torch.rand(B, L, 1, generator=g) - 0.5) * SW * 0.5 * t_ + 60 * torch.sin(6 * t_ + x0)
+    ys = SH * (1 - 0.9 * t_).expand(B, L, P)
+    lanes = torch.stack([xs, ys], -1).to(dev)
+    lane_maps = [torch.empty_like(hm) for hm, _, _ in scales]
+
+    def step_lanes():
+        for (hm, c, r), lm, s in zip(scales, lane_maps, (4, 8, 16)):
+            draw_heatmap_batched(hm, c, r, 6.0, 1.0, clear=True)
+            draw_polylines_batched(lm, lanes, 1024 // s, 2, float(s), clear=True)
+
+    t2 = _timeit(step_lanes, 50, 500, torch.cuda.synchronize)
+    print(json.dumps({"config": "C3+lanes", "metric": "C3 + lane raster (8 lanes x 24 pts, 256/128/64 samples, r=2) per scale",
+                      "ms_per_batch": t2 * 1e3, "frames_per_s": B / t2, "GBps": 2 * nbytes / t2 / 1e9,
+                      "bytes_per_frame": 2 * nbytes // B, "lane_part_ms": (t2 - t) * 1e3,
+                      "hipgraph_ms_per_batch": (tg2 := _graph_time(step_lanes)) * 1e3,
+                      "hipgraph_frames_per_s": B / tg2}))
 
 
 def h2():
@@ -194,9 +233,44 @@ def h2():
                       "compaction_speedup": t_ct / t_ck}))
 
 
+def f3():
+    """Loss-side caller pattern (examples/matched_loss.py): batched formulation over this build's ragged
+    operators vs the per-sample loop, forward + backward, assignment (scipy, CPU) included in both and also timed
+    without it."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import matched_loss as ml
+    import accvlab.batching_helpers as bh
+
+    dev = torch.device("cuda", 0)
+    B, Q, C, G = 8, 900, 10, 100
+    gb, gl, gw, pb, ps, pe = ml.make_inputs(B, Q, C, G, dev, seed=0, min_gt=1)
+    sync = torch.cuda.synchronize
+
+    def fwd_bwd(fn):
+        leaves = [t.clone().requires_grad_(True) for t in (pb, ps, pe)]
+        fn(gb, gl, gw, *leaves).sum().backward()
+
+    t_b = _timeit(lambda: fwd_bwd(ml.run_batched), 3, 20, sync)
+    t_l = _timeit(lambda: fwd_bwd(ml.loss_per_sample), 3, 20, sync)
+    # loss only (matches precomputed): isolates the ragged gathers/scatters from the CPU assignment
+    boxes = bh.combine_data(gb)
+    labels = bh.combine_data(gl, other_with_same_sample_sizes=boxes)
+    weights = bh.combine_data(gw, other_with_same_sample_sizes=boxes)
+    m_gt, m_pred = ml.match_batched(boxes, labels, pb, ps)
+
+    def loss_only():
+        leaves = [t.clone().requires_grad_(True) for t in (pb, ps, pe)]
+        ml.loss_batched(boxes, labels, weights, *leaves, m_gt, m_pred).sum().backward()
+
+    t_lo = _timeit(loss_only, 5, 50, sync)
+    print(json.dumps({"config": "F3", "shape": {"batch": B, "queries": Q, "classes": C, "max_gt": G},
+                      "batched_fwd_bwd_ms": t_b * 1e3, "per_sample_loop_fwd_bwd_ms": t_l * 1e3,
+                      "speedup": t_l / t_b, "batched_loss_only_fwd_bwd_ms": t_lo * 1e3}))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="C0,C2,C3,H2")
+    ap.add_argument("--configs", default="C0,C2,C3,H2,F3")
     ap.add_argument("--tensors", type=int, default=10_000)
     a = ap.parse_args()
     which = a.configs.split(",")
@@ -210,3 +284,5 @@ if __name__ == "__main__":
             c3()
         if "H2" in which:
             h2()
+        if "F3" in which:
+            f3()

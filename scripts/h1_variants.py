@@ -23,10 +23,14 @@ def main():
     ap.add_argument("--rule", default="A")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--warm", type=int, default=300, help="untimed launches of a variant before its timed ones")
     ap.add_argument("--knobs", default="hm_wpg=1,4;hm_nt=0,4",
-                    help="knobs understood by libaccv_hip: hm_kernel=1|2, hm_nw=16|8, hm_wpg=1|4, hm_rows=8|16, hm_nt=0|1|2|4")
+                    help="knobs understood by libaccv_hip: hm_wpg=1|4, hm_rows=8|16, hm_nt=0|1|2|4")
     ap.add_argument("--empty", action="store_true", help="no objects: isolates the store pattern")
     ap.add_argument("--nmin", type=int, default=1, help="minimum objects per frame (128 = densest case)")
+    ap.add_argument("--alt-lib", default=None,
+                    help="second build of libaccv_hip.so (e.g. the previous commit's) timed beside the shipped one in the "
+                         "same process: A/B of CODE changes on one box, since boxes differ by more than most changes")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     B, H, W = args.batch, 1080, 1920
@@ -48,7 +52,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def timed(fn):
-        for _ in range(5):
+        # warm up with the SAME variant for ~30 ms: the clocks follow the instruction mix of the last tens of
+        # milliseconds, so a compute-heavier variant timed right after a store-only one reads up to 10 % slow
+        for _ in range(args.warm):
             fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -58,6 +64,20 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / args.iters
+
+    alt = None
+    if args.alt_lib:
+        import ctypes
+
+        alt = ctypes.CDLL(os.path.abspath(args.alt_lib))
+        fn = alt.accv_draw_heatmap_batched_f32
+        fn.restype, fn.argtypes = nat.SIGNATURES["accv_draw_heatmap_batched_f32"]
+        i64 = nat.HM_COUNTS_I64 if c.sample_sizes.dtype == torch.int64 else 0
+
+        def draw_with(handle, clear):
+            handle.accv_draw_heatmap_batched_f32(hm.data_ptr(), B, 0, H, W, c.tensor.data_ptr(), r.tensor.data_ptr(),
+                                                 c.sample_sizes.data_ptr(), None, r.tensor.shape[1], 6.0, 1.0,
+                                                 (nat.HM_CLEAR if clear else 0) | i64, stream)
 
     res = {}
     for rnd in range(args.rounds):
@@ -71,6 +91,13 @@ def main():
             for mode in ("clear", "inplace"):
                 t = timed(lambda: draw_heatmap_batched(hm, c, r, 6.0, 1.0, clear=(mode == "clear")))
                 res.setdefault(var + (mode,), []).append(t)
+        if alt is not None:  # both builds through the bare C-ABI, default knobs
+            for k, v in (("hm_wpg", 1), ("hm_rows", 8), ("hm_nt", -1)):
+                nat.tune_set(k, v)
+            for mode in ("clear", "inplace"):
+                for name, handle in (("shipped", lib), ("alt", alt)):
+                    t = timed(lambda: draw_with(handle, mode == "clear"))
+                    res.setdefault((name + "-lib", mode), []).append(t)
     for key, ts in res.items():
         ts = sorted(ts)
         med = ts[len(ts) // 2]

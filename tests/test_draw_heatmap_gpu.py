@@ -22,14 +22,21 @@ def rb(t, sizes):
     return SimpleNamespace(tensor=t, sample_sizes=sizes)
 
 
-@pytest.fixture(autouse=True, params=[1, 2], ids=["wave-tiles", "row-pair-waves"])
+_VARIANTS = {"shipped": {}, "rows16": {"hm_rows": 16}, "wpg4": {"hm_wpg": 4}}
+_DEFAULTS = {"hm_rows": 8, "hm_wpg": 1}
+
+
+@pytest.fixture(autouse=True, params=list(_VARIANTS), ids=list(_VARIANTS))
 def kernel_variant(request):
-    """every test of this module runs against both splat kernels (tune knob hm_kernel)"""
+    """every test of this module runs against the shipped splat-kernel instantiation and the alternative ones that
+    the tune knobs can select (tile rows, waves per workgroup)"""
     from accvlab import _amd_native as nat
 
-    nat.tune_set("hm_kernel", request.param)
+    for k, v in _VARIANTS[request.param].items():
+        nat.tune_set(k, v)
     yield request.param
-    nat.tune_set("hm_kernel", 1)
+    for k, v in _DEFAULTS.items():
+        nat.tune_set(k, v)
 
 
 def _dh():

@@ -1,0 +1,103 @@
+"""Lane raster (BASELINE config 3: "lane_helpers polyline raster") — GPU parity.
+
+The reference has no polyline rasteriser, so there is no reference output to pin the composed op against; parity is
+checked stage by stage against the two pinned oracles it is built from:
+  1. the arc-length samples                      vs  oracle.lane.sample (pinned by tests/golden/lane_polyline.npz), 1e-5 (scaled)
+  2. float sample -> int centre / radius         vs  the rule of _test_helpers.py:20-28 (trunc(p / stride)), bit-exact
+  3. the drawn map from THOSE integer targets    vs  oracle.h1 (pinned by tests/golden/h1_g*.npz), 1e-5 abs
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import h1 as oracle_h1
+from oracle import lane as oracle_lane
+
+pytestmark = pytest.mark.gpu
+
+
+def _lanes(b, l, p, w, h, seed, ragged):
+    g = np.random.default_rng(seed)
+    start = g.uniform([0, 0], [w, h], size=(b, l, 1, 2))
+    steps = g.normal(0, 1, size=(b, l, p, 2)) * [w / p / 2, h / p / 2] + [w / p / 3, -h / p / 4]
+    pts = (start + np.cumsum(steps, axis=2)).astype(np.float32)
+    npts = g.integers(0, p + 1, size=(b, l)).astype(np.int64) if ragged else None
+    nlanes = g.integers(0, l + 1, size=(b,)).astype(np.int64) if ragged else None
+    return pts, npts, nlanes
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+@pytest.mark.parametrize("stride,radius,q", [(4.0, 2, 64), (1.0, 1, 17), (16.0, 3, 1)])
+def test_lane_raster_stages(ragged, stride, radius, q):
+    from accvlab.draw_heatmap import draw_polylines_batched, sample_lane_targets
+    from accvlab.lane_helpers.polyline import interpolate_var_size_batch
+    from accvlab.batching_helpers import RaggedBatch
+
+    dev = torch.device("cuda", 0)
+    b, l, p, sw, sh = 3, 5, 12, 960.0, 540.0
+    h, w = int(sh / stride), int(sw / stride)
+    pts, npts, nlanes = _lanes(b, l, p, sw, sh, seed=int(stride) * 10 + q, ragged=ragged)
+    pts_d = torch.from_numpy(pts).to(dev)
+    npts_d = torch.from_numpy(npts).to(dev) if ragged else None
+    nlanes_d = torch.from_numpy(nlanes).to(dev) if ragged else None
+
+    # stage 1: samples vs the lane oracle
+    frac = np.linspace(0.0, 1.0, q).astype(np.float32) if q > 1 else np.zeros(1, np.float32)
+    pr = RaggedBatch(pts_d.view(b * l, p, 2), sample_sizes=(npts_d.view(-1) if ragged else
+                                                            torch.full((b * l,), p, device=dev, dtype=torch.int64)))
+    dr = RaggedBatch(torch.from_numpy(np.tile(frac, (b * l, 1))).to(dev),
+                     sample_sizes=torch.full((b * l,), q, device=dev, dtype=torch.int64))
+    got = interpolate_var_size_batch(pr, dr, relative=True).tensor.cpu().numpy().reshape(b, l, q, 2)
+    for i in range(b):
+        for j in range(l):
+            n = int(npts[i, j]) if ragged else p
+            want = oracle_lane.sample(pts[i, j, :n], frac, relative=True)
+            if n == 0:
+                assert np.isnan(got[i, j]).all()
+            else:
+                assert np.abs(got[i, j] - want).max() <= 1e-5 * max(sw, sh)   # coordinates are O(1e3): relative 1e-5
+
+    # stage 2: integer targets from the kernel's own samples, bit-exact
+    centers, radii = sample_lane_targets(pts_d, q, radius, stride, num_points=npts_d)
+    c = centers.cpu().numpy().reshape(b, l, q, 2)
+    r = radii.cpu().numpy().reshape(b, l, q)
+    bad = np.isnan(got).any(-1)
+    want_c = np.where(bad[..., None], 0, np.trunc(np.nan_to_num(got) / np.float32(stride))).astype(np.int32)
+    assert np.array_equal(c, want_c)
+    assert np.array_equal(r, np.where(bad, -1, radius))
+
+    # stage 3: composed draw vs the heat-map oracle on the same integer targets (in place on a non-zero map, and clear)
+    sizes = (nlanes * q) if ragged else np.full(b, l * q, dtype=np.int64)
+    base = np.random.default_rng(1).uniform(0, 0.3, size=(b, h, w)).astype(np.float32)
+    for clear in (False, True):
+        hm = torch.from_numpy(base.copy()).to(dev)
+        draw_polylines_batched(hm, pts_d, q, radius, stride, 6.0, 0.9, num_points=npts_d, num_lanes=nlanes_d,
+                               clear=clear)
+        ref = base.copy()
+        oracle_h1.draw_heatmap_batched(ref, centers.cpu().numpy(), radii.cpu().numpy(), sizes, k=0.9, clear=clear)
+        assert np.abs(hm.cpu().numpy() - ref).max() <= 1e-5
+        if not ragged and q > 1:
+            assert (hm.cpu().numpy() > base if not clear else hm.cpu().numpy() > 0).any()   # something was drawn
+
+
+def test_lane_raster_validation_and_empty():
+    from accvlab.draw_heatmap import draw_polylines_batched, sample_lane_targets
+
+    dev = torch.device("cuda", 0)
+    with pytest.raises(RuntimeError):
+        sample_lane_targets(torch.zeros(2, 3, 4, 2), 8, 1)                       # CPU tensor
+    with pytest.raises(RuntimeError):
+        sample_lane_targets(torch.zeros(2, 3, 4, 3, device=dev), 8, 1)           # not [.., 2]
+    with pytest.raises(RuntimeError):
+        sample_lane_targets(torch.zeros(2, 3, 4, 2, device=dev, dtype=torch.float64), 8, 1)
+    with pytest.raises(RuntimeError):
+        sample_lane_targets(torch.zeros(2, 3, 4, 2, device=dev), 0, 1)
+    c, r = sample_lane_targets(torch.zeros(2, 0, 4, 2, device=dev), 8, 1)
+    assert c.shape == (2, 0, 2) and r.shape == (2, 0)
+    hm = torch.full((2, 16, 16), 0.25, device=dev)
+    draw_polylines_batched(hm, torch.zeros(2, 0, 4, 2, device=dev), 8, 1)       # no lanes: map untouched
+    assert (hm == 0.25).all()
+    # all lanes empty (zero points) -> NaN samples -> nothing drawn
+    draw_polylines_batched(hm, torch.zeros(2, 3, 4, 2, device=dev), 8, 2,
+                           num_points=torch.zeros(2, 3, dtype=torch.int32, device=dev))
+    assert (hm == 0.25).all()
