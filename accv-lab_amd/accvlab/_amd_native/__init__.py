@@ -52,6 +52,7 @@ SIGNATURES = {
     "accv_pinned_trim": (None, []),
     "accv_pinned_total_bytes": (_sz, []),
     "accv_mtc_worker_count": (_i, []),
+    "accv_mtc_pack_host": (_i, [_ll, _vp, _vp, _vp, _vp, _ll]),
     "accv_mtc_stage_h2d": (_i, [_ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _i]),
     "accv_mtc_coalesce": (_i, [_vp, _ll, _vp, _i, _vp]),
     "accv_memcpy_async": (_i, [_vp, _vp, _sz, _i, _vp]),

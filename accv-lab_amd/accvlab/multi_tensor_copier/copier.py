@@ -192,6 +192,7 @@ class _Job:
         self.caller_stream = None
         self.source_events = {}
         self.released = False
+        self.packed = None               # PackedBatch whose buffer still has to travel (host->GPU)
 
     def release_staging(self):
         if not self.released:
@@ -228,6 +229,9 @@ def _run(job: _Job) -> None:
 
     if to_gpu:
         side = _side_stream(dev)
+        if job.packed is not None and job.packed.num_packed:
+            with torch.cuda.device(dev):
+                _enqueue_packed_batch(job, lib, side)
         packable = np.nonzero(route == R_H2D_PACK)[0].astype(np.int64)
         single = np.nonzero(route == R_H2D_SINGLE)[0].tolist()
         d2d = np.nonzero(route == R_D2D)[0].tolist()
@@ -321,6 +325,44 @@ def _run(job: _Job) -> None:
                 done = torch.cuda.Event()
                 done.record(side)
                 job.events.append(done)
+
+
+def _enqueue_packed_batch(job: _Job, lib, side) -> None:
+    """Host->GPU for a PackedBatch: the packing already happened in the producer (DataLoader worker), so this is ONE
+    transfer of its buffer — straight from the buffer when it is pinned, through one arena block otherwise — and the
+    typed views on the GPU chunk."""
+    pk, dev = job.packed, job.device
+    size = pk.buffer.numel()
+    align = pk.alignment
+    with torch.cuda.stream(job.caller_stream):
+        g = torch.empty(size + align + 15, dtype=torch.uint8, device=dev)
+        base = (-g.data_ptr()) % align
+        ready = torch.cuda.Event()
+        ready.record(job.caller_stream)
+    side.wait_event(ready)
+    dst = g.data_ptr() + base
+    if pk.buffer.is_pinned() or not job.pinned:
+        _nat.check(lib.accv_memcpy_async(dst, pk.buffer.data_ptr(), size, 1, side.cuda_stream), "memcpy_async")
+    else:
+        stage = lib.accv_pinned_acquire(size)
+        if not stage:
+            _nat.check(-4, "pinned arena")
+        job.staging.append(stage)
+        # the worker pool splits at item boundaries: present the buffer as 1 MiB slices
+        piece = 1 << 20
+        m = (size + piece - 1) // piece
+        off = np.arange(m, dtype=np.int64) * piece
+        nb = np.minimum(piece, size - off).astype(np.int64)
+        src = (np.uint64(pk.buffer.data_ptr()) + off.astype(np.uint64)).astype(np.uint64)
+        order = np.arange(m, dtype=np.int64)
+        begin = np.array([0, m], dtype=np.int64)
+        one = lambda v, t: np.array([v], dtype=t)  # noqa: E731
+        stage_a, dev_a, csz = one(stage, np.uint64), one(dst, np.uint64), one(size, np.int64)
+        _nat.check(lib.accv_mtc_stage_h2d(m, src.ctypes.data, nb.ctypes.data, off.ctypes.data, order.ctypes.data, 1,
+                                          begin.ctypes.data, stage_a.ctypes.data, dev_a.ctypes.data, csz.ctypes.data,
+                                          side.cuda_stream, 0), "mtc_stage_h2d")
+    job.tree.views_on(g, int(base), pk._leaf_ids, pk._offsets, pk._dtypes, pk._ndims, pk._shapes, False)
+    job.keep.append(g)
 
 
 def _coalesced_d2h(job: _Job, lib, small: np.ndarray, sdev: torch.device, side) -> bool:
@@ -419,7 +461,8 @@ def start_copy(data, device, *, use_pinned_staging: bool = True, pack_cpu_tensor
 
     Args:
         data: a tensor / numpy array or a nesting of ``list`` / ``tuple`` / ``dict`` with tensor, array and arbitrary
-            other leaves (the latter are passed through unchanged; other container types count as opaque leaves).
+            other leaves (the latter are passed through unchanged; other container types count as opaque leaves);
+            or (extension) a :class:`PackedBatch` made by ``pack_batch`` / ``packing_collate`` in a DataLoader worker.
         device: target device (``"cuda:0"``, ``"cpu"``, ``torch.device``).
         use_pinned_staging: stage host<->GPU transfers through pinned memory (host->GPU becomes asynchronous;
             GPU->host returns the pinned buffer itself).
@@ -441,9 +484,18 @@ def start_copy(data, device, *, use_pinned_staging: bool = True, pack_cpu_tensor
         _nat.lib()  # fail loudly if the HIP library is missing
     elif dev.type != "cpu":
         raise RuntimeError(f"Invalid device string: {device!r}")
-    tree = _make_leaf_set(data)
+    from .packed import PackedBatch
+
+    packed = data if isinstance(data, PackedBatch) else None
+    if packed is not None:
+        # produced by pack_batch / packing_collate: the small tensors already sit in one buffer
+        tree = packed._tree(cpu_views=dev.type != "cuda")
+    else:
+        tree = _make_leaf_set(data)
     job = _Job(tree, dev, bool(use_pinned_staging), bool(pack_cpu_tensors), int(min_packed_alignment_bytes),
                int(max_packed_chunk_bytes))
+    if packed is not None and dev.type == "cuda":
+        job.packed = packed              # also keeps the buffer alive until the handle is consumed
     job.meta = tree.classify(str(dev), job.pack)
     route, _, _, _, didx = job.meta
     # ordering: capture the caller's current streams NOW (reference :1086-1123)

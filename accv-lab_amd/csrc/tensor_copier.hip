@@ -311,6 +311,23 @@ int accv_mtc_worker_count(void) { return WorkerPool::instance().size() + 1; }
  * staging[c] + offset[i] using up to `threads` workers, then hipMemcpyAsync(device[c], staging[c], chunk_bytes[c])
  * host->device on `stream`.  Items must be grouped so that item_begin[c]..item_begin[c+1] index `order`.
  * device[c] == NULL skips the transfer (staging only).  Does not synchronise the stream. */
+int accv_mtc_pack_host(long long n_items, const void* const* src, const long long* nbytes, const long long* offset,
+                       void* dst, long long dst_bytes)
+{
+    if (n_items < 0) return accv::fail(ACCV_EINVAL, "mtc_pack_host: negative count");
+    if (n_items == 0) return ACCV_OK;
+    if (!src || !nbytes || !offset || !dst) return accv::fail(ACCV_EINVAL, "mtc_pack_host: null array");
+    char* base = static_cast<char*>(dst);
+    // plain loop on the calling thread, no HIP call and no pool: this runs inside forked DataLoader workers, where
+    // neither the parent's worker threads nor its HIP context exist
+    for (long long i = 0; i < n_items; ++i) {
+        if (nbytes[i] < 0 || offset[i] < 0 || offset[i] + nbytes[i] > dst_bytes)
+            return accv::fail(ACCV_EINVAL, "mtc_pack_host: item %lld does not fit the buffer", i);
+        if (nbytes[i]) std::memcpy(base + offset[i], src[i], (size_t)nbytes[i]);
+    }
+    return ACCV_OK;
+}
+
 int accv_mtc_stage_h2d(long long n_items, const void* const* src, const long long* nbytes, const long long* offset,
                        const long long* order, long long n_chunks, const long long* item_begin, void* const* staging,
                        void* const* device, const long long* chunk_bytes, void* stream_, int threads)

@@ -22,7 +22,7 @@ constexpr int64_t kPackMaxBytes = 256 * 1024;  // multi_tensor_copier.cpp:483
 enum Kind : uint8_t { kList = 0, kTuple = 1, kDict = 2, kLeaf = 3, kPass = 4 };
 
 // classification of a leaf relative to the target device
-enum Route : int8_t { kReuse = 0, kH2DPack = 1, kH2DSingle = 2, kD2HSmall = 3, kD2HOther = 4, kD2D = 5, kOther = 6 };
+enum Route : int8_t { kExternal = -1, kReuse = 0, kH2DPack = 1, kH2DSingle = 2, kD2HSmall = 3, kD2HOther = 4, kD2D = 5, kOther = 6 };
 
 struct Op {
     uint8_t kind;
@@ -37,6 +37,112 @@ public:
         ndarray_type_ = py::module_::import("numpy").attr("ndarray");
         walk(data);
         outs_.resize(leaves_.size());
+    }
+    Tree() = default;  // filled by from_spec
+
+    // ---- serialisable form (PackedBatch: the structure travels between processes without its packed leaves)
+    // (kinds uint8[M], args int64[M], objects list) — the flat pre-order op list itself
+    py::tuple export_spec() const
+    {
+        py::array_t<uint8_t> kinds((py::ssize_t)ops_.size());
+        py::array_t<int64_t> args((py::ssize_t)ops_.size());
+        auto k = kinds.mutable_unchecked<1>();
+        auto a = args.mutable_unchecked<1>();
+        for (size_t i = 0; i < ops_.size(); ++i) {
+            k((py::ssize_t)i) = ops_[i].kind;
+            a((py::ssize_t)i) = ops_[i].arg;
+        }
+        py::list objs;
+        for (const auto& o : objects_) objs.append(o);
+        return py::make_tuple(kinds, args, objs);
+    }
+
+    static Tree from_spec(const py::array_t<uint8_t>& kinds, const py::array_t<int64_t>& args, const py::list& objects,
+                          int64_t num_leaves)
+    {
+        Tree t;
+        auto k = kinds.unchecked<1>();
+        auto a = args.unchecked<1>();
+        TORCH_CHECK(k.shape(0) == a.shape(0), "spec arrays differ in length");
+        t.ops_.reserve((size_t)k.shape(0));
+        int64_t leaves = 0;
+        for (py::ssize_t i = 0; i < k.shape(0); ++i) {
+            TORCH_CHECK(k(i) <= kPass, "bad op kind in spec");
+            if (k(i) == kLeaf) {
+                TORCH_CHECK(a(i) == leaves, "leaf ids of a spec must be consecutive");
+                ++leaves;
+            }
+            t.ops_.push_back({k(i), a(i)});
+        }
+        TORCH_CHECK(leaves == num_leaves, "spec holds ", leaves, " leaves, expected ", num_leaves);
+        for (const auto& o : objects) t.objects_.push_back(py::reinterpret_borrow<py::object>(o));
+        t.leaves_.resize((size_t)num_leaves);
+        t.outs_.resize((size_t)num_leaves);
+        return t;
+    }
+
+    void set_leaf(int64_t i, const at::Tensor& t) { leaves_.at((size_t)i) = t; }
+
+    // (scalar type int8[k], ndim int8[k], sizes int64[sum ndim]) of the given (contiguous) leaves
+    py::tuple leaf_meta(const py::array_t<int64_t>& idx) const
+    {
+        auto ix = idx.unchecked<1>();
+        py::array_t<int8_t> dtypes(ix.shape(0)), ndims(ix.shape(0));
+        auto d = dtypes.mutable_unchecked<1>();
+        auto n = ndims.mutable_unchecked<1>();
+        std::vector<int64_t> sizes;
+        for (py::ssize_t k = 0; k < ix.shape(0); ++k) {
+            const at::Tensor& t = leaves_.at((size_t)ix(k));
+            TORCH_CHECK(t.dim() < 128, "too many dimensions");
+            d(k) = (int8_t)t.scalar_type();
+            n(k) = (int8_t)t.dim();
+            for (auto s : t.sizes()) sizes.push_back(s);
+        }
+        py::array_t<int64_t> shapes((py::ssize_t)sizes.size());
+        std::copy(sizes.begin(), sizes.end(), shapes.mutable_data());
+        return py::make_tuple(dtypes, ndims, shapes);
+    }
+
+    // contiguous typed views on `storage_holder`'s storage at byte `base + offsets[k]` for leaves idx[k], described by
+    // leaf_meta arrays; stored as outputs, and (as_leaves) also as the leaves themselves (CPU unpack of a PackedBatch)
+    void views_on(const at::Tensor& storage_holder, int64_t base, const py::array_t<int64_t>& idx,
+                  const py::array_t<int64_t>& offsets, const py::array_t<int8_t>& dtypes, const py::array_t<int8_t>& ndims,
+                  const py::array_t<int64_t>& shapes, bool as_leaves)
+    {
+        auto ix = idx.unchecked<1>();
+        auto of = offsets.unchecked<1>();
+        auto dt = dtypes.unchecked<1>();
+        auto nd = ndims.unchecked<1>();
+        auto sh = shapes.unchecked<1>();
+        TORCH_CHECK(of.shape(0) == ix.shape(0) && dt.shape(0) == ix.shape(0) && nd.shape(0) == ix.shape(0),
+                    "packed metadata arrays differ in length");
+        const int64_t storage_bytes = (int64_t)storage_holder.storage().nbytes();
+        py::ssize_t cursor = 0;
+        std::vector<int64_t> sizes;
+        for (py::ssize_t k = 0; k < ix.shape(0); ++k) {
+            const auto st = static_cast<at::ScalarType>(dt(k));
+            const caffe2::TypeMeta meta = c10::scalarTypeToTypeMeta(st);
+            const int64_t es = (int64_t)meta.itemsize();
+            sizes.assign((size_t)nd(k), 0);
+            int64_t numel = 1;
+            TORCH_CHECK(cursor + nd(k) <= sh.shape(0), "shape array too short");
+            for (int j = 0; j < nd(k); ++j) {
+                sizes[(size_t)j] = sh(cursor++);
+                TORCH_CHECK(sizes[(size_t)j] >= 0, "negative size in packed metadata");
+                numel *= sizes[(size_t)j];
+            }
+            const int64_t byte_off = storage_holder.storage_offset() * (int64_t)storage_holder.element_size() + base + of(k);
+            TORCH_CHECK(byte_off % es == 0, "packed offset ", byte_off, " is not a multiple of the element size ", es);
+            TORCH_CHECK(byte_off >= 0 && byte_off + numel * es <= storage_bytes, "packed leaf lies outside the buffer");
+            auto impl = c10::make_intrusive<at::TensorImpl>(c10::Storage(storage_holder.storage()),
+                                                            storage_holder.key_set(), meta);
+            impl->set_sizes_contiguous(sizes);
+            impl->set_storage_offset(byte_off / es);
+            at::Tensor view(std::move(impl));
+            const size_t li = (size_t)ix(k);
+            outs_.at(li) = view;
+            if (as_leaves) leaves_.at(li) = view;
+        }
     }
 
     int64_t num_leaves() const { return (int64_t)leaves_.size(); }
@@ -60,6 +166,14 @@ public:
         auto d = dev.mutable_unchecked<1>();
         for (int64_t i = 0; i < n; ++i) {
             const at::Tensor& t = leaves_[(size_t)i];
+            if (!t.defined()) {  // packed leaf of a PackedBatch: lives in the batch buffer, produced by views_on
+                r(i) = kExternal;
+                b(i) = 0;
+                e(i) = 1;
+                p(i) = 0;
+                d(i) = -1;
+                continue;
+            }
             const int64_t bytes = t.numel() * (int64_t)t.element_size();
             b(i) = bytes;
             e(i) = (int32_t)t.element_size();
@@ -208,5 +322,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         .def("set_out", &Tree::set_out)
         .def("classify", &Tree::classify)
         .def("make_packed_views", &Tree::make_packed_views)
+        .def("export_spec", &Tree::export_spec)
+        .def_static("from_spec", &Tree::from_spec)
+        .def("set_leaf", &Tree::set_leaf)
+        .def("leaf_meta", &Tree::leaf_meta)
+        .def("views_on", &Tree::views_on)
         .def("rebuild", &Tree::rebuild);
 }

@@ -162,6 +162,13 @@ void accv_pinned_trim(void);
 size_t accv_pinned_total_bytes(void);
 int accv_mtc_worker_count(void);
 
+/* DataLoader hook: host-only pack of `n_items` buffers into `dst` at the byte offsets of accv_mtc_plan
+ * (single chunk).  Plain memcpy loop on the calling thread; makes no HIP call and uses no worker pool, so it is safe
+ * inside forked DataLoader worker processes.  No reference counterpart (the reference packs in the consumer process,
+ * fill_cpu_staging_buffers, multi_tensor_copier.cpp:647-679). */
+int accv_mtc_pack_host(long long n_items, const void* const* src, const long long* nbytes, const long long* offset,
+                       void* dst, long long dst_bytes);
+
 /* fill_cpu_staging_buffers + enqueue_packed_transfer (multi_tensor_copier.cpp:647-679, 683-730): per chunk c,
  * memcpy src[i] -> staging[c] + offset[i] for i in order[item_begin[c] .. item_begin[c+1]) on up to `threads`
  * workers, then one hipMemcpyAsync(device[c] <- staging[c], chunk_bytes[c]) on `stream` (skipped when device[c]
