@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Reduce the three rocprofv3 passes of scripts/collect_profiles.sh to one JSON: average duration of the splat kernel
+(all launches and the last 500 = bench.py's timed region), WRITE_SIZE / FETCH_SIZE per launch with the gfx950
+corrections of MI355X_MICROARCH.md (FETCH_SIZE doubled), next to bench.py's own HIP-event figure from the same run."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def rows(pattern):
+    files = glob.glob(pattern, recursive=True)
+    if not files:
+        return []
+    with open(files[0]) as f:
+        return list(csv.DictReader(f))
+
+
+def main(out):
+    res = {}
+    trace = rows(os.path.join(out, "trace", "**", "*kernel_trace.csv"))
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace
+           if "splat_kernel" in r["Kernel_Name"] and "true" in r["Kernel_Name"].split("splat_kernel")[1][:20]]
+    if dur:
+        res["clear_kernel"] = {"name": next(r["Kernel_Name"] for r in trace if "splat_kernel" in r["Kernel_Name"]),
+                               "launches": len(dur), "avg_us_all": sum(dur) / len(dur) / 1e3,
+                               "avg_us_last500": sum(dur[-500:]) / len(dur[-500:]) / 1e3}
+    stats = rows(os.path.join(out, "trace", "**", "*kernel_stats.csv"))
+    res["kernel_stats_top"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage")}
+                               for r in stats[:6]]
+    for key, sub, counter in (("write", "write", "WRITE_SIZE"), ("fetch", "fetch", "FETCH_SIZE")):
+        cr = rows(os.path.join(out, sub, "**", "*counter_collection.csv"))
+        per = {}
+        for r in cr:
+            if r.get("Counter_Name") != counter or "splat_kernel" not in r["Kernel_Name"]:
+                continue
+            mode = "clear" if ", true," in r["Kernel_Name"] else "inplace"
+            per.setdefault(mode, []).append(float(r["Counter_Value"]))
+        res[counter + "_KB_per_launch"] = {m: sum(v) / len(v) for m, v in per.items()}
+    w = res.get("WRITE_SIZE_KB_per_launch", {}).get("clear")
+    f = res.get("FETCH_SIZE_KB_per_launch", {}).get("clear")
+    if w is not None and f is not None:
+        res["hbm_bytes_per_launch_clear"] = int(w * 1024 + 2 * f * 1024)   # FETCH_SIZE doubled on gfx950
+    wi = res.get("WRITE_SIZE_KB_per_launch", {}).get("inplace")
+    fi = res.get("FETCH_SIZE_KB_per_launch", {}).get("inplace")
+    if wi is not None and fi is not None:
+        res["hbm_bytes_per_launch_inplace"] = int(wi * 1024 + 2 * fi * 1024)
+    try:
+        with open(os.path.join(out, "bench_under_rocprof.json")) as fh:
+            line = [l for l in fh.read().splitlines() if l.startswith("{")][-1]
+        b = json.loads(line)
+        res["bench_under_rocprof"] = {"ms_per_step": b["ms_per_step"], "kernel_ms": b["roofline"].get("kernel_ms"),
+                                      "frac": b["roofline"]["frac"], "value": b["value"]}
+    except Exception as e:  # noqa: BLE001
+        res["bench_under_rocprof"] = f"unreadable: {e}"
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
