@@ -38,6 +38,7 @@ SIGNATURES = {
     "accv_heatmap_targets_from_points_f32": (_i, [_vp, _ll, _f, _i, _vp, _vp, _vp]),
     # H2 ragged kernels
     "accv_ragged_gather": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp, _vp]),
+    "accv_ragged_gather_fill": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _u64, _i, _i, _i, _vp, _vp]),
     "accv_ragged_scatter": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp, _vp]),
     "accv_ragged_map_pairs": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp, _vp]),
     "accv_ragged_insert_const": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _u64, _i, _i, _i, _vp, _vp]),
@@ -106,4 +107,27 @@ def stream_ptr(device) -> int:
     at::cuda::getCurrentCUDAStream(), draw_heatmap_cuda.cu:65)."""
     import torch
 
-    return torch.cuda.current_stream(device).cuda_stream
+    idx = device.index
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device):
+    """Context manager that makes `device` current for a launch (the reference's at::DeviceGuard,
+    draw_heatmap_cuda.cu:64) — free when it already is, which is the case in one-process-per-GPU training."""
+    import torch
+
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(idx)

@@ -9,6 +9,7 @@ There is no CPU path in this module (the reference's is CUDA-only too).
 """
 from __future__ import annotations
 
+import functools
 import struct
 from typing import Optional, Sequence
 
@@ -27,60 +28,74 @@ def _req(cond: bool, msg: str) -> None:
 
 
 def _contig(t: torch.Tensor, name: str) -> None:
-    _req(t.is_contiguous(), f"{name} must be contiguous")
+    if not (t.is_contiguous()):
+        raise RuntimeError(f"{name} must be contiguous")
 
 
 def _same_cuda_device(*named) -> None:
     name0, first = named[0]
-    _req(first.is_cuda, f"{name0} must be a CUDA tensor")
+    if not (first.is_cuda):
+        raise RuntimeError(f"{name0} must be a CUDA tensor")
     for _, t in named[1:]:
-        _req(t.device == first.device, "All input tensors must be on the same device")
+        if not (t.device == first.device):
+            raise RuntimeError("All input tensors must be on the same device")
 
 
 def _dims_at_least(t, n, name):
     if t.numel() != 0:
-        _req(t.dim() >= n, f"{name} must have at least {n} dimensions")
+        if not (t.dim() >= n):
+            raise RuntimeError(f"{name} must have at least {n} dimensions")
 
 
 def _dims_exact(t, n, name):
     if t.numel() != 0:
-        _req(t.dim() == n, f"{name} must have {n} dimensions")
+        if not (t.dim() == n):
+            raise RuntimeError(f"{name} must have {n} dimensions")
 
 
 def _match_first(a, b, n, na, nb_):
     if a.numel() == 0 and b.numel() == 0:
         return
-    _req(a.dim() >= n and b.dim() >= n, f"{na} and {nb_} must have at least {n} dimensions")
+    if not (a.dim() >= n and b.dim() >= n):
+        raise RuntimeError(f"{na} and {nb_} must have at least {n} dimensions")
     for i in range(n):
-        _req(a.size(i) == b.size(i), f"{na} and {nb_} must have the same size in dimension {i}")
+        if not (a.size(i) == b.size(i)):
+            raise RuntimeError(f"{na} and {nb_} must have the same size in dimension {i}")
 
 
 def _match_except(a, b, dim, na, nb_):
     if a.numel() == 0 and b.numel() == 0:
         return
-    _req(a.dim() == b.dim(), f"{na} and {nb_} must have the same number of dimensions")
+    if not (a.dim() == b.dim()):
+        raise RuntimeError(f"{na} and {nb_} must have the same number of dimensions")
     for i in range(a.dim()):
         if i != dim:
-            _req(a.size(i) == b.size(i), f"{na} and {nb_} must have the same size in dimension {i}")
+            if not (a.size(i) == b.size(i)):
+                raise RuntimeError(f"{na} and {nb_} must have the same size in dimension {i}")
 
 
 def _match_all(a, b, na, nb_):
     if a.numel() == 0 and b.numel() == 0:
         return
-    _req(a.dim() == b.dim(), f"{na} and {nb_} must have the same number of dimensions")
-    _req(tuple(a.shape) == tuple(b.shape), f"{na} and {nb_} must have the same size")
+    if not (a.dim() == b.dim()):
+        raise RuntimeError(f"{na} and {nb_} must have the same number of dimensions")
+    if not (tuple(a.shape) == tuple(b.shape)):
+        raise RuntimeError(f"{na} and {nb_} must have the same size")
 
 
 def _index_dtype(t, name) -> int:
-    _req(t.dtype in _INDEX_DTYPES, f"{name}: index tensors must be int32 or int64, got {t.dtype}")
+    if not (t.dtype in _INDEX_DTYPES):
+        raise RuntimeError(f"{name}: index tensors must be int32 or int64, got {t.dtype}")
     return 1 if t.dtype == torch.int64 else 0
 
 
 def _data_dtype(t, name, allow_bool=False) -> None:
     ok = t.dtype in _COPY_DTYPES or (allow_bool and t.dtype == torch.bool)
-    _req(ok, f"{name}: unsupported data type {t.dtype}")
+    if not (ok):
+        raise RuntimeError(f"{name}: unsupported data type {t.dtype}")
 
 
+@functools.lru_cache(maxsize=256)
 def element_bits(value, dtype: torch.dtype) -> int:
     """Byte pattern (as an unsigned integer, little endian) of ``value`` converted to ``dtype`` with the
     conversion rules of ``static_cast<scalar_t>(double)`` used by the reference."""
@@ -116,7 +131,7 @@ def _call(status: int, what: str) -> None:
 
 
 def _stream(t: torch.Tensor) -> int:
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _nat.stream_ptr(t.device)
 
 
 # ------------------------------------------------------------------------------------------------ forward
@@ -135,21 +150,26 @@ def forward(input_data: torch.Tensor, input_indices: torch.Tensor, input_nums_in
     _dims_at_least(input_data, nb + 1, "input_data")
     _match_first(input_data, input_indices, nb, "input_data", "input_indices")
     _match_first(input_indices, input_nums_indices, nb, "input_indices", "input_nums_indices")
-    _req(input_indices.dim() >= nb + 1, f"input_indices must have at least {nb + 1} dimensions")
+    if not (input_indices.dim() >= nb + 1):
+        raise RuntimeError(f"input_indices must have at least {nb + 1} dimensions")
     _data_dtype(input_data, "input_data")
     res_size = list(input_indices.shape[:nb + 1]) + list(input_data.shape[nb + 1:])
-    res = torch.full(res_size, fill_value, dtype=input_data.dtype, device=input_data.device,
-                     requires_grad=input_data.requires_grad)
-    if input_indices.numel() == 0 or res.numel() == 0:
-        return res
+    if input_indices.numel() == 0 or 0 in res_size:
+        return torch.full(res_size, fill_value, dtype=input_data.dtype, device=input_data.device,
+                          requires_grad=input_data.requires_grad)
+    # the kernel writes every element of the result (gathered rows and the filler): no torch.full pass
+    res = torch.empty(res_size, dtype=input_data.dtype, device=input_data.device,
+                      requires_grad=input_data.requires_grad)
     batch = _batch_numel(input_nums_indices)
     w_idx = input_indices.size(nb)
-    row_bytes = _row_elems(input_data, nb + 1) * input_data.element_size()
-    with torch.cuda.device(input_data.device):
-        _call(_nat.lib().accv_ragged_gather(
+    esz = input_data.element_size()
+    row_bytes = _row_elems(input_data, nb + 1) * esz
+    with _nat.device_guard(input_data.device):
+        _call(_nat.lib().accv_ragged_gather_fill(
             input_data.data_ptr(), res.data_ptr(), input_indices.data_ptr(), input_nums_indices.data_ptr(), batch,
-            input_data.size(nb), w_idx, w_idx, row_bytes, _index_dtype(input_indices, "input_indices"),
-            _index_dtype(input_nums_indices, "input_nums_indices"), None, _stream(input_data)), "forward")
+            input_data.size(nb), w_idx, w_idx, row_bytes, element_bits(fill_value, input_data.dtype), esz,
+            _index_dtype(input_indices, "input_indices"), _index_dtype(input_nums_indices, "input_nums_indices"), None,
+            _stream(input_data)), "forward")
     return res
 
 
@@ -160,13 +180,14 @@ def _scatter_into(res, to_insert, indices, counts, nb, accumulate, clear_first, 
     esz = to_insert.element_size()
     ii, ci = _index_dtype(indices, "input_indices"), _index_dtype(counts, "input_nums_indices")
     lib = _nat.lib()
-    with torch.cuda.device(res.device):
+    with _nat.device_guard(res.device):
         s = _stream(res)
         if not accumulate:
             _call(lib.accv_ragged_scatter(to_insert.data_ptr(), res.data_ptr(), indices.data_ptr(), counts.data_ptr(),
                                           batch, w_idx, w_idx, res.size(nb), elems * esz, ii, ci, None, s), what)
         else:
-            _req(to_insert.dtype in _ACC_CODE, f"{what}: accumulation is not supported for {to_insert.dtype}")
+            if not (to_insert.dtype in _ACC_CODE):
+                raise RuntimeError(f"{what}: accumulation is not supported for {to_insert.dtype}")
             if clear_first:
                 _call(lib.accv_ragged_insert_const(res.data_ptr(), indices.data_ptr(), counts.data_ptr(), batch, w_idx,
                                                    w_idx, res.size(nb), elems * esz, 0, esz, ii, ci, None, s), what)
@@ -192,7 +213,8 @@ def backward_new_tensor(to_insert: torch.Tensor, input_indices: torch.Tensor, in
     _dims_exact(input_indices, nb + 1, "input_indices")
     _match_first(to_insert, input_indices, nb, "to_insert", "input_indices")
     _match_first(input_indices, input_nums_indices, nb, "input_indices", "input_nums_indices")
-    _req(to_insert.dim() >= nb + 1, f"to_insert must have at least {nb + 1} dimensions")
+    if not (to_insert.dim() >= nb + 1):
+        raise RuntimeError(f"to_insert must have at least {nb + 1} dimensions")
     _data_dtype(to_insert, "to_insert")
     shape = list(to_insert.shape)
     shape[nb] = int(input_num_targets)
@@ -213,7 +235,8 @@ def backward_insert(to_insert: torch.Tensor, input_indices: torch.Tensor, input_
         _contig(t, n)
     _same_cuda_device(("to_insert", to_insert), ("input_indices", input_indices),
                       ("input_nums_indices", input_nums_indices), ("to_insert_into", to_insert_into))
-    _req(to_insert.dtype == to_insert_into.dtype, "Same dtype required for `to_insert` and `to_insert_into`")
+    if not (to_insert.dtype == to_insert_into.dtype):
+        raise RuntimeError("Same dtype required for `to_insert` and `to_insert_into`")
     _dims_at_least(input_nums_indices, 1, "input_nums_indices")
     nb = input_nums_indices.dim()
     _dims_at_least(to_insert, nb + 1, "to_insert")
@@ -253,7 +276,7 @@ def backward_insert_const(to_insert: float, input_indices: torch.Tensor, input_n
 def _insert_const(res, value, indices, counts, nb, what):
     esz = res.element_size()
     w_idx = indices.size(nb)
-    with torch.cuda.device(res.device):
+    with _nat.device_guard(res.device):
         _call(_nat.lib().accv_ragged_insert_const(
             res.data_ptr(), indices.data_ptr(), counts.data_ptr(), _batch_numel(counts), w_idx, w_idx, res.size(nb),
             _row_elems(res, nb + 1) * esz, element_bits(value, res.dtype), esz, _index_dtype(indices, "input_indices"),
@@ -271,7 +294,8 @@ def map_values_by_index_pairs(input_data: torch.Tensor, input_indices: torch.Ten
     _same_cuda_device(("input_data", input_data), ("input_indices", input_indices),
                       ("output_indices", output_indices), ("nums_indices", nums_indices),
                       ("to_insert_into", to_insert_into))
-    _req(input_data.dtype == to_insert_into.dtype, "Same dtype required for `input_data` and `to_insert_into`")
+    if not (input_data.dtype == to_insert_into.dtype):
+        raise RuntimeError("Same dtype required for `input_data` and `to_insert_into`")
     _dims_at_least(nums_indices, 1, "nums_indices")
     nb = nums_indices.dim()
     _dims_at_least(input_data, nb + 1, "input_data")
@@ -282,7 +306,8 @@ def map_values_by_index_pairs(input_data: torch.Tensor, input_indices: torch.Ten
     _match_first(input_indices, nums_indices, nb, "input_indices", "nums_indices")
     _match_except(input_data, to_insert_into, nb, "input_data", "to_insert_into")
     _data_dtype(to_insert_into, "to_insert_into")
-    _req(input_indices.dtype == output_indices.dtype, "input_indices and output_indices must have the same dtype")
+    if not (input_indices.dtype == output_indices.dtype):
+        raise RuntimeError("input_indices and output_indices must have the same dtype")
     res = to_insert_into.clone()
     if input_indices.numel() == 0 or res.numel() == 0 or input_data.numel() == 0:
         return res
@@ -291,7 +316,7 @@ def map_values_by_index_pairs(input_data: torch.Tensor, input_indices: torch.Ten
     batch, w_idx = _batch_numel(nums_indices), input_indices.size(nb)
     elems, esz = _row_elems(res, nb + 1), res.element_size()
     lib = _nat.lib()
-    with torch.cuda.device(res.device):
+    with _nat.device_guard(res.device):
         s = _stream(res)
         if not backward_accumulate:
             _call(lib.accv_ragged_map_pairs(input_data.data_ptr(), res.data_ptr(), input_indices.data_ptr(),
@@ -299,7 +324,8 @@ def map_values_by_index_pairs(input_data: torch.Tensor, input_indices: torch.Ten
                                             input_data.size(nb), w_idx, w_idx, res.size(nb), elems * esz, ii, ci, None,
                                             s), "map_values_by_index_pairs")
         else:
-            _req(res.dtype in _ACC_CODE, f"map_values_by_index_pairs: accumulation is not supported for {res.dtype}")
+            if not (res.dtype in _ACC_CODE):
+                raise RuntimeError(f"map_values_by_index_pairs: accumulation is not supported for {res.dtype}")
             _call(lib.accv_ragged_insert_const(res.data_ptr(), output_indices.data_ptr(), nums_indices.data_ptr(), batch,
                                                w_idx, w_idx, res.size(nb), elems * esz, 0, esz, ii, ci, None, s),
                   "map_values_by_index_pairs")
@@ -340,7 +366,7 @@ def set_ragged_batch_padded_to_filler_value_in_place(data: torch.Tensor, nums_va
     if data.numel() == 0:
         return
     esz = data.element_size()
-    with torch.cuda.device(data.device):
+    with _nat.device_guard(data.device):
         _call(_nat.lib().accv_ragged_pad_fill(
             data.data_ptr(), nums_valid_entries.data_ptr(), _batch_numel(nums_valid_entries), data.size(nb),
             _row_elems(data, nb + 1) * esz, element_bits(filler_value, data.dtype), esz,
@@ -353,8 +379,10 @@ def mask_to_indices(mask: torch.Tensor, valid_counts: Optional[torch.Tensor] = N
     """(extension, no reference counterpart in the native layer) positions of the True entries of every row
     of a 2-D mask, in order, as int64 ``[B, M]`` zero-filled behind, plus int64 counts ``[B]`` — the
     wave-ballot compaction that replaces torch boolean indexing in batched_bool_indexing."""
-    _req(mask.is_cuda, "mask must be a CUDA tensor")
-    _req(mask.dim() == 2, "mask must be 2-D")
+    if not (mask.is_cuda):
+        raise RuntimeError("mask must be a CUDA tensor")
+    if not (mask.dim() == 2):
+        raise RuntimeError("mask must be 2-D")
     m = mask if mask.dtype == torch.bool else mask != 0
     m = m.contiguous()
     b, w = m.shape
@@ -362,11 +390,12 @@ def mask_to_indices(mask: torch.Tensor, valid_counts: Optional[torch.Tensor] = N
     sizes = torch.empty((b,), dtype=torch.int64, device=m.device)
     vc_ptr, vc64 = None, 0
     if valid_counts is not None:
-        _req(valid_counts.device == m.device and valid_counts.numel() == b, "valid_counts must match the mask rows")
+        if not (valid_counts.device == m.device and valid_counts.numel() == b):
+            raise RuntimeError("valid_counts must match the mask rows")
         valid_counts = valid_counts.contiguous()
         vc_ptr, vc64 = valid_counts.data_ptr(), _index_dtype(valid_counts, "valid_counts")
     if b > 0:
-        with torch.cuda.device(m.device):
+        with _nat.device_guard(m.device):
             _call(_nat.lib().accv_ragged_mask_to_indices(m.data_ptr(), vc_ptr, vc64, b, w, idx.data_ptr(),
                                                          sizes.data_ptr(), _stream(m)), "mask_to_indices")
     return idx, sizes
@@ -375,11 +404,12 @@ def mask_to_indices(mask: torch.Tensor, valid_counts: Optional[torch.Tensor] = N
 def gather_rows(src: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor, w_idx: int, out: torch.Tensor) -> None:
     """(extension) ``out[i, j] = src[i, indices[i, j]]`` for j < counts[i], j < w_idx, where ``indices`` may be
     wider than ``w_idx`` (row stride = indices.size(1)); any dtype incl. bool; single batch dimension."""
-    _req(src.is_contiguous() and out.is_contiguous() and indices.is_contiguous(), "gather_rows: contiguous tensors required")
+    if not (src.is_contiguous() and out.is_contiguous() and indices.is_contiguous()):
+        raise RuntimeError("gather_rows: contiguous tensors required")
     if out.numel() == 0 or w_idx == 0:
         return
     row_bytes = _row_elems(src, 2) * src.element_size()
-    with torch.cuda.device(src.device):
+    with _nat.device_guard(src.device):
         _call(_nat.lib().accv_ragged_gather(src.data_ptr(), out.data_ptr(), indices.data_ptr(), counts.data_ptr(),
                                             src.size(0), src.size(1), int(w_idx), indices.size(1), row_bytes,
                                             _index_dtype(indices, "indices"), _index_dtype(counts, "counts"), None,
@@ -388,11 +418,12 @@ def gather_rows(src: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor, 
 
 def scatter_rows(src: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor, w_idx: int, out: torch.Tensor) -> None:
     """(extension) ``out[i, indices[i, j]] = src[i, j]`` for j < counts[i], j < w_idx (src width == w_idx)."""
-    _req(src.is_contiguous() and out.is_contiguous() and indices.is_contiguous(), "scatter_rows: contiguous tensors required")
+    if not (src.is_contiguous() and out.is_contiguous() and indices.is_contiguous()):
+        raise RuntimeError("scatter_rows: contiguous tensors required")
     if src.numel() == 0 or w_idx == 0:
         return
     row_bytes = _row_elems(src, 2) * src.element_size()
-    with torch.cuda.device(src.device):
+    with _nat.device_guard(src.device):
         _call(_nat.lib().accv_ragged_scatter(src.data_ptr(), out.data_ptr(), indices.data_ptr(), counts.data_ptr(),
                                              src.size(0), int(w_idx), indices.size(1), out.size(1), row_bytes,
                                              _index_dtype(indices, "indices"), _index_dtype(counts, "counts"), None,
@@ -401,7 +432,8 @@ def scatter_rows(src: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor,
 
 def pack_rows(flat: torch.Tensor, offsets: torch.Tensor, sizes: torch.Tensor, width: int) -> torch.Tensor:
     """(extension) padded ``[B, width, *inner]`` from ``flat [total, *inner]`` — combine_data on the device."""
-    _req(flat.is_cuda and flat.is_contiguous(), "pack_rows: flat must be a contiguous CUDA tensor")
+    if not (flat.is_cuda and flat.is_contiguous()):
+        raise RuntimeError("pack_rows: flat must be a contiguous CUDA tensor")
     b = sizes.numel()
     out = torch.empty((b, int(width)) + tuple(flat.shape[1:]), dtype=flat.dtype, device=flat.device)
     if out.numel() == 0:
@@ -409,7 +441,7 @@ def pack_rows(flat: torch.Tensor, offsets: torch.Tensor, sizes: torch.Tensor, wi
     if flat.numel() == 0:
         return out.zero_()
     row_bytes = _row_elems(flat, 1) * flat.element_size()
-    with torch.cuda.device(flat.device):
+    with _nat.device_guard(flat.device):
         _call(_nat.lib().accv_ragged_pack(flat.data_ptr(), out.data_ptr(), offsets.data_ptr(), sizes.data_ptr(), b,
                                           int(width), row_bytes, 0, _stream(flat)), "pack_rows")
     return out

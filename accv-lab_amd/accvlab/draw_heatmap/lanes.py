@@ -36,17 +36,23 @@ def sample_lane_targets(polylines: torch.Tensor, num_samples: int, radius: int, 
     """``polylines`` f32 ``[B, L, P, 2]`` (x, y in source pixels; ``num_points`` int ``[B, L]`` = valid points per
     lane, default all) -> ``(centers i32 [B, L*num_samples, 2], radii i32 [B, L*num_samples])`` at the heat-map stride
     ``out_size_factor``: ``c = int(sample / stride)``.  Samples of empty lanes get radius -1 (never drawn)."""
-    _require(isinstance(polylines, torch.Tensor) and polylines.is_cuda, "polylines must be a CUDA tensor")
-    _require(polylines.dim() == 4 and polylines.size(3) == 2, "polylines must be of shape [batch, lanes, points, 2]")
-    _require(polylines.dtype == torch.float32, f"polylines: expected float32 but found {polylines.dtype}")
-    _require(num_samples >= 1, "num_samples must be >= 1")
+    if not (isinstance(polylines, torch.Tensor) and polylines.is_cuda):
+        raise RuntimeError("polylines must be a CUDA tensor")
+    if not (polylines.dim() == 4 and polylines.size(3) == 2):
+        raise RuntimeError("polylines must be of shape [batch, lanes, points, 2]")
+    if not (polylines.dtype == torch.float32):
+        raise RuntimeError(f"polylines: expected float32 but found {polylines.dtype}")
+    if not (num_samples >= 1):
+        raise RuntimeError("num_samples must be >= 1")
     b, l, p, _ = polylines.shape
     dev = polylines.device
     pts = polylines.contiguous().view(b * l, p, 2)
     counts = None
     if num_points is not None:
-        _require(num_points.shape == (b, l), "num_points must be of shape [batch, lanes]")
-        _require(num_points.device == dev, "num_points must be on the same device as polylines")
+        if not (num_points.shape == (b, l)):
+            raise RuntimeError("num_points must be of shape [batch, lanes]")
+        if not (num_points.device == dev):
+            raise RuntimeError("num_points must be on the same device as polylines")
         _poly._check_sizes(num_points.reshape(-1), p, "num_points")
         counts = num_points.contiguous().view(b * l)
     centers = torch.empty((b, l * num_samples, 2), dtype=torch.int32, device=dev)
@@ -58,7 +64,7 @@ def sample_lane_targets(polylines: torch.Tensor, num_samples: int, radius: int, 
         0.0, 1.0, num_samples, device=dev).unsqueeze(0).expand(b * l, num_samples).contiguous()
         if num_samples > 1 else torch.zeros((b * l, 1), device=dev))
     samples = _poly._gpu(pts, frac, counts, None, True, True, False)[0]
-    with torch.cuda.device(dev):
+    with _nat.device_guard(dev):
         _nat.check(_nat.lib().accv_heatmap_targets_from_points_f32(
             samples.data_ptr(), b * l * num_samples, float(out_size_factor), int(radius), centers.data_ptr(),
             radii.data_ptr(), _nat.stream_ptr(dev)), "sample_lane_targets")
@@ -81,7 +87,8 @@ def draw_polylines_batched(heatmap: torch.Tensor, polylines: torch.Tensor, num_s
         sizes = _cached(("full", b, l * num_samples, heatmap.device),
                         lambda: torch.full((b,), l * num_samples, dtype=torch.int32, device=heatmap.device))
     else:
-        _require(num_lanes.shape == (b,), "num_lanes must be of shape [batch]")
+        if not (num_lanes.shape == (b,)):
+            raise RuntimeError("num_lanes must be of shape [batch]")
         sizes = num_lanes.clamp(0, l) * num_samples
     draw_heatmap_batched(heatmap, SimpleNamespace(tensor=centers, sample_sizes=sizes),
                          SimpleNamespace(tensor=radii, sample_sizes=sizes), diameter_to_sigma_factor, k_scale,

@@ -21,18 +21,23 @@ def _require(cond: bool, msg: str) -> None:
 
 
 def _check_input(t: torch.Tensor, name: str) -> None:
-    _require(isinstance(t, torch.Tensor), f"{name} must be a torch.Tensor")
-    _require(t.is_cuda, f"{name} must be a CUDA tensor")
-    _require(t.is_contiguous(), f"{name} must be contiguous")
+    if not (isinstance(t, torch.Tensor)):
+        raise RuntimeError(f"{name} must be a torch.Tensor")
+    if not (t.is_cuda):
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not (t.is_contiguous()):
+        raise RuntimeError(f"{name} must be contiguous")
 
 
 def _check_dtype(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
-    _require(t.dtype == dtype, f"{name}: expected scalar type {dtype} but found {t.dtype}")
+    if not (t.dtype == dtype):
+        raise RuntimeError(f"{name}: expected scalar type {dtype} but found {t.dtype}")
 
 
 def _same_device(ref: torch.Tensor, *others) -> None:
     for name, t in others:
-        _require(t.device == ref.device, f"{name} must be on the same device as the heatmap ({ref.device})")
+        if not (t.device == ref.device):
+            raise RuntimeError(f"{name} must be on the same device as the heatmap ({ref.device})")
 
 
 def draw_heatmap(
@@ -62,11 +67,16 @@ def draw_heatmap(
     _check_input(centers, "centers")
     _check_input(radii, "radii")
     _check_input(heatmap_idxes, "heatmap_idxes")
-    _require(centers.size(0) == radii.size(0), "centers and radii must have the same size at dim0")
-    _require(centers.size(0) == heatmap_idxes.size(0), "centers and heatmap_idxes must have the same size at dim0")
-    _require(heatmaps.dim() == 3, "heatmap must be of shape [num_heatmaps, height, width]")
-    _require(centers.dim() == 2 and centers.size(1) == 2, "centers must be of shape [num_targets, 2]")
-    _require(radii.dim() == 1 and heatmap_idxes.dim() == 1, "radii and heatmap_idxes must be of shape [num_targets]")
+    if not (centers.size(0) == radii.size(0)):
+        raise RuntimeError("centers and radii must have the same size at dim0")
+    if not (centers.size(0) == heatmap_idxes.size(0)):
+        raise RuntimeError("centers and heatmap_idxes must have the same size at dim0")
+    if not (heatmaps.dim() == 3):
+        raise RuntimeError("heatmap must be of shape [num_heatmaps, height, width]")
+    if not (centers.dim() == 2 and centers.size(1) == 2):
+        raise RuntimeError("centers must be of shape [num_targets, 2]")
+    if not (radii.dim() == 1 and heatmap_idxes.dim() == 1):
+        raise RuntimeError("radii and heatmap_idxes must be of shape [num_targets]")
     _check_dtype(heatmaps, torch.float32, "heatmap")
     _check_dtype(centers, torch.int32, "centers")
     _check_dtype(radii, torch.int32, "radii")
@@ -76,7 +86,7 @@ def draw_heatmap(
     lib = _nat.lib()
     planes, height, width = heatmaps.shape
     n = centers.size(0)
-    with torch.cuda.device(heatmaps.device):
+    with _nat.device_guard(heatmaps.device):
         ws_bytes = lib.accv_draw_heatmap_flat_workspace_bytes(planes, n)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=heatmaps.device)
         status = lib.accv_draw_heatmap_flat_f32(
@@ -138,27 +148,35 @@ def draw_heatmap_batched(
     n_max = radii_t.size(1) if radii_t.dim() >= 2 else -1
     _require(batch == radii_t.size(0) and batch == centers_t.size(0) and batch == counts.size(0),
              "batch_size (dim 0) need to be the same for all inputs")
-    _require(centers_t.dim() == 3 and centers_t.size(2) == 2, "centers must be of shape [batch_size, num_targets, 2]")
-    _require(radii_t.dim() == 2, "radii must be of shape [batch_size, num_targets]")
-    _require(n_max == centers_t.size(1), "maximum number of targets (dim 1) need to be the same centers and radii")
-    _require(counts.dim() == 1, "nums_targets must be of shape [batch_size]")
+    if not (centers_t.dim() == 3 and centers_t.size(2) == 2):
+        raise RuntimeError("centers must be of shape [batch_size, num_targets, 2]")
+    if not (radii_t.dim() == 2):
+        raise RuntimeError("radii must be of shape [batch_size, num_targets]")
+    if not (n_max == centers_t.size(1)):
+        raise RuntimeError("maximum number of targets (dim 1) need to be the same centers and radii")
+    if not (counts.dim() == 1):
+        raise RuntimeError("nums_targets must be of shape [batch_size]")
     _check_dtype(heatmap, torch.float32, "heatmap")
     _check_dtype(centers_t, torch.int32, "centers")
     _check_dtype(radii_t, torch.int32, "radii")
     others = [("centers", centers_t), ("radii", radii_t), ("nums_targets", counts)]
     if labels_t is None:
-        _require(heatmap.dim() == 3, "heatmap must be of shape [batch_size, height, width]")
+        if not (heatmap.dim() == 3):
+            raise RuntimeError("heatmap must be of shape [batch_size, height, width]")
         num_classes, (height, width) = 0, heatmap.shape[1:]
         labels_ptr = None
     else:
         _check_input(labels_t, "labels")
-        _require(heatmap.dim() == 4, "heatmap must be of shape [batch_size, max_num_classes, height, width]")
-        _require(labels_t.dim() == 2, "labels must be of shape [batch_size, radii.size(1)]")
+        if not (heatmap.dim() == 4):
+            raise RuntimeError("heatmap must be of shape [batch_size, max_num_classes, height, width]")
+        if not (labels_t.dim() == 2):
+            raise RuntimeError("labels must be of shape [batch_size, radii.size(1)]")
         _require(labels_t.size(0) == batch and labels_t.size(1) == n_max,
                  "labels shape must be [batch_size, radii.size(1)]")
         _check_dtype(labels_t, torch.int32, "labels")
         num_classes, height, width = heatmap.shape[1:]
-        _require(num_classes > 0 or heatmap.numel() == 0, "class-wise heatmap needs at least one class plane")
+        if not (num_classes > 0 or heatmap.numel() == 0):
+            raise RuntimeError("class-wise heatmap needs at least one class plane")
         labels_ptr = labels_t.data_ptr()
         others.append(("labels", labels_t))
     _same_device(heatmap, *others)
@@ -166,7 +184,7 @@ def draw_heatmap_batched(
         return
 
     flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0)
-    with torch.cuda.device(heatmap.device):
+    with _nat.device_guard(heatmap.device):
         status = _nat.lib().accv_draw_heatmap_batched_f32(
             heatmap.data_ptr(), batch, num_classes, height, width, centers_t.data_ptr(), radii_t.data_ptr(),
             counts.data_ptr(), labels_ptr, n_max, float(diameter_to_sigma_factor), float(k_scale), flags,
@@ -189,12 +207,13 @@ def get_centers_and_radii(centers, bboxes, out_size_factor: float):
     _require(c_t.shape[-1] == 2 and b_t.shape[-1] == 4 and c_t.shape[:-1] == b_t.shape[:-1],
              "centers must be [..., 2] and bboxes [..., 4] with equal leading dimensions")
     if c_t.is_cuda:
-        _require(b_t.device == c_t.device, "centers and bboxes must be on the same device")
+        if not (b_t.device == c_t.device):
+            raise RuntimeError("centers and bboxes must be on the same device")
         c32 = c_t.to(torch.float32).contiguous()
         b32 = b_t.to(torch.float32).contiguous()
         out_c = torch.empty(c32.shape, dtype=torch.int32, device=c32.device)
         out_r = torch.empty(c32.shape[:-1], dtype=torch.int32, device=c32.device)
-        with torch.cuda.device(c32.device):
+        with _nat.device_guard(c32.device):
             _nat.check(_nat.lib().accv_heatmap_targets_from_boxes_f32(
                 c32.data_ptr(), b32.data_ptr(), out_r.numel(), float(out_size_factor), out_c.data_ptr(),
                 out_r.data_ptr(), _nat.stream_ptr(c32.device)), "get_centers_and_radii")

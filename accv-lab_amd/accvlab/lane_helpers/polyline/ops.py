@@ -19,15 +19,20 @@ def _req(cond, msg):
 
 
 def _check_points(points, name="points"):
-    _req(isinstance(points, torch.Tensor), f"{name} must be a tensor")
-    _req(points.device.type in ("cpu", "cuda"), f"{name} must be a CPU or CUDA tensor")
+    if not (isinstance(points, torch.Tensor)):
+        raise RuntimeError(f"{name} must be a tensor")
+    if not (points.device.type in ("cpu", "cuda")):
+        raise RuntimeError(f"{name} must be a CPU or CUDA tensor")
     ok = points.dtype in _DTYPE_CODE if points.is_cuda else points.dtype in (torch.float32, torch.float64)
-    _req(ok, f"{name} has an unsupported dtype {points.dtype}")
+    if not (ok):
+        raise RuntimeError(f"{name} has an unsupported dtype {points.dtype}")
 
 
 def _check_sizes(sizes, limit, name):
-    _req(sizes.dtype in (torch.int32, torch.int64), f"{name} must be int32 or int64")
-    _req(sizes.dim() == 1, f"{name} must be a 1D tensor")
+    if not (sizes.dtype in (torch.int32, torch.int64)):
+        raise RuntimeError(f"{name} must be int32 or int64")
+    if not (sizes.dim() == 1):
+        raise RuntimeError(f"{name} must be a 1D tensor")
 
 
 def _gpu(points, distances, p_sizes, d_sizes, relative, want_points, want_lengths):
@@ -47,7 +52,7 @@ def _gpu(points, distances, p_sizes, d_sizes, relative, want_points, want_length
         c64 = 1 if p_sizes.dtype == torch.int64 else 0
     if d_sizes is not None:
         d_sizes = d_sizes.contiguous()
-    with torch.cuda.device(points.device):
+    with _nat.device_guard(points.device):
         sb = lib.accv_polyline_scratch_bytes(b, pmax, code)
         scratch = torch.empty(sb, dtype=torch.uint8, device=points.device) if sb else None
         _nat.check(lib.accv_polyline_sample(
@@ -121,11 +126,16 @@ def interpolate(points: torch.Tensor, distances: torch.Tensor, *, relative: bool
     start / beyond the end clamp to the first / last point.  Returns ``(batch, num_distances, num_dims)``."""
     _check_points(points)
     _check_points(distances, "distances")
-    _req(points.dim() == 3, "points must have shape (batch, num_points, num_dims)")
-    _req(distances.dim() == 2, "distances must have shape (batch, num_distances)")
-    _req(points.size(0) == distances.size(0), "points and distances must contain the same number of polylines")
-    _req(points.dtype == distances.dtype, "points and distances must have the same dtype")
-    _req(points.device == distances.device, "points and distances must be on the same device")
+    if not (points.dim() == 3):
+        raise RuntimeError("points must have shape (batch, num_points, num_dims)")
+    if not (distances.dim() == 2):
+        raise RuntimeError("distances must have shape (batch, num_distances)")
+    if not (points.size(0) == distances.size(0)):
+        raise RuntimeError("points and distances must contain the same number of polylines")
+    if not (points.dtype == distances.dtype):
+        raise RuntimeError("points and distances must have the same dtype")
+    if not (points.device == distances.device):
+        raise RuntimeError("points and distances must be on the same device")
     if points.is_cuda:
         return _gpu(points, distances, None, None, relative, True, False)[0]
     return _cpu_interpolate(points, distances, None, None, relative)
@@ -134,7 +144,8 @@ def interpolate(points: torch.Tensor, distances: torch.Tensor, *, relative: bool
 def lengths(points: torch.Tensor) -> torch.Tensor:
     """Total length of every polyline of ``points (batch, num_points, num_dims)`` -> ``(batch,)``."""
     _check_points(points)
-    _req(points.dim() == 3, "points must have shape (batch, num_points, num_dims)")
+    if not (points.dim() == 3):
+        raise RuntimeError("points must have shape (batch, num_points, num_dims)")
     if points.is_cuda:
         return _gpu(points, None, None, None, False, False, True)[1]
     return _cpu_lengths(points, None)
@@ -142,8 +153,10 @@ def lengths(points: torch.Tensor) -> torch.Tensor:
 
 def _check_var(points, sizes, name):
     _check_sizes(sizes, points.size(1), name)
-    _req(sizes.device == points.device, f"{name} must be on the same device as its tensor")
-    _req(sizes.size(0) == points.size(0), f"{name} must contain one count per polyline")
+    if not (sizes.device == points.device):
+        raise RuntimeError(f"{name} must be on the same device as its tensor")
+    if not (sizes.size(0) == points.size(0)):
+        raise RuntimeError(f"{name} must contain one count per polyline")
 
 
 def interpolate_var_size_batch(points, distances, *, relative: bool = False):
@@ -157,11 +170,16 @@ def interpolate_var_size_batch(points, distances, *, relative: bool = False):
     pt, dt, ps, ds = points.tensor, distances.tensor, points.sample_sizes, distances.sample_sizes
     _check_points(pt)
     _check_points(dt, "distances")
-    _req(pt.dim() == 3, "points must have shape (batch, max_num_points, num_dims)")
-    _req(dt.dim() == 2, "distances must have shape (batch, max_num_distances)")
-    _req(pt.size(0) == dt.size(0), "points and distances must contain the same number of polylines")
-    _req(pt.dtype == dt.dtype, "points and distances must have the same dtype")
-    _req(pt.device == dt.device, "points and distances must be on the same device")
+    if not (pt.dim() == 3):
+        raise RuntimeError("points must have shape (batch, max_num_points, num_dims)")
+    if not (dt.dim() == 2):
+        raise RuntimeError("distances must have shape (batch, max_num_distances)")
+    if not (pt.size(0) == dt.size(0)):
+        raise RuntimeError("points and distances must contain the same number of polylines")
+    if not (pt.dtype == dt.dtype):
+        raise RuntimeError("points and distances must have the same dtype")
+    if not (pt.device == dt.device):
+        raise RuntimeError("points and distances must be on the same device")
     _req(ps.dtype == ds.dtype, "points.sample_sizes and distances.sample_sizes must have the same dtype "
                                "(both int32 or both int64)")
     _check_var(pt, ps, "points.sample_sizes")
@@ -179,7 +197,8 @@ def lengths_var_size_batch(points) -> torch.Tensor:
     assert points.non_uniform_dim == 1, "points.non_uniform_dim must be 1 for shape (batch, max_num_points, num_dims)"
     pt, ps = points.tensor, points.sample_sizes
     _check_points(pt)
-    _req(pt.dim() == 3, "points must have shape (batch, max_num_points, num_dims)")
+    if not (pt.dim() == 3):
+        raise RuntimeError("points must have shape (batch, max_num_points, num_dims)")
     _check_var(pt, ps, "points.sample_sizes")
     if pt.is_cuda:
         return _gpu(pt, None, ps, None, False, False, True)[1]

@@ -107,6 +107,28 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const RaggedDesc d, cons
     }
 }
 
+// gather that also writes the filler: dst[i, j, :] = src[i, idx[i,j], :] for valid (i, j), `pattern` elsewhere, so the
+// caller hands over an UNINITIALISED result (one launch instead of torch::full + gather, cpp:82-85)
+template <int VB>
+__global__ __launch_bounds__(256) void gather_fill_kernel(const RaggedDesc d, const void* __restrict__ src_,
+                                                          void* __restrict__ dst_, typename VecOf<VB>::type pattern)
+{
+    using V = typename VecOf<VB>::type;
+    const V* src = static_cast<const V*>(src_);
+    V* dst = static_cast<V*>(dst_);
+    const long long total = d.batch * d.w_idx * d.row_vecs;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long pair = t / d.row_vecs, v = t - pair * d.row_vecs;
+        const long long i = pair / d.w_idx, j = pair - i * d.w_idx;
+        V val = pattern;
+        if (j < load_int(d.counts, i, d.counts_i64)) {
+            const long long s = wrap_index(load_int(d.idx_a, i * d.idx_stride + j, d.idx_i64), d.w_src, d.err);
+            if (s >= 0) val = src[(i * d.w_src + s) * d.row_vecs + v];
+        }
+        dst[t] = val;
+    }
+}
+
 // dst[i, idx[i,j], :] = pattern
 template <int VB>
 __global__ __launch_bounds__(256) void insert_const_kernel(const RaggedDesc d, void* __restrict__ dst_,
@@ -339,6 +361,27 @@ int accv_ragged_gather(const void* src, void* dst, const void* indices, const vo
 {
     return run_copy(kGather, src, dst, indices, nullptr, counts, batch, w_idx, idx_stride, w_src, w_idx, row_bytes,
                     idx_i64, counts_i64, err_counter, static_cast<hipStream_t>(stream), "ragged_gather");
+}
+
+int accv_ragged_gather_fill(const void* src, void* dst, const void* indices, const void* counts, long long batch,
+                            long long w_src, long long w_idx, long long idx_stride, long long row_bytes,
+                            uint64_t fill_bits, int elem_size, int idx_i64, int counts_i64, int* err_counter,
+                            void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = check_desc("ragged_gather_fill", batch, w_idx, idx_stride, row_bytes, indices, counts)) return rc;
+    if (elem_size != 1 && elem_size != 2 && elem_size != 4 && elem_size != 8)
+        return accv::fail(ACCV_EINVAL, "ragged_gather_fill: unsupported element size %d", elem_size);
+    if (batch * w_idx * row_bytes == 0) return ACCV_OK;
+    if (!src || !dst) return accv::fail(ACCV_EINVAL, "ragged_gather_fill: null data pointer");
+    const int vb = pick_vec(row_bytes, {src, dst});
+    if (vb < elem_size) return accv::fail(ACCV_EINVAL, "ragged_gather_fill: data not aligned to its element size");
+    RaggedDesc d{indices, nullptr, counts, batch, w_idx, idx_stride, w_src, w_idx, row_bytes / vb, idx_i64, counts_i64,
+                 err_counter};
+    const unsigned grid = grid_for(batch * w_idx * d.row_vecs);
+    DISPATCH_VB(vb, hipLaunchKernelGGL((gather_fill_kernel<VB>), dim3(grid), dim3(256), 0, stream, d, src, dst,
+                                       make_pattern<VB>(fill_bits, elem_size)));
+    return accv::check_launch("ragged_gather_fill");
 }
 
 int accv_ragged_scatter(const void* src, void* dst, const void* indices, const void* counts, long long batch,

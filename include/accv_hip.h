@@ -92,6 +92,14 @@ int accv_ragged_gather(const void* src, void* dst, const void* indices, const vo
                        long long w_src, long long w_idx, long long idx_stride, long long row_bytes, int idx_i64,
                        int counts_i64, int* err_counter, void* stream);
 
+/* The same gather, but the kernel also writes the filler: dst[i, j, :] = `fill_bits` pattern (element of `elem_size`
+ * in {1,2,4,8} bytes, little endian) for j >= counts[i] and for skipped out-of-range indices, so dst may be
+ * uninitialised — one launch for torch::full + indexing_kernel of batched_indexing_access_cuda.cpp:82-85. */
+int accv_ragged_gather_fill(const void* src, void* dst, const void* indices, const void* counts, long long batch,
+                            long long w_src, long long w_idx, long long idx_stride, long long row_bytes,
+                            uint64_t fill_bits, int elem_size, int idx_i64, int counts_i64, int* err_counter,
+                            void* stream);
+
 /* dst[i, indices[i,j], :] = src[i, j, :]   — overwrite direction of indexing_kernel (cpp:88-146 with
  * backward_accumulate == false).  src [batch, w_idx, row], dst [batch, w_dst, row]. */
 int accv_ragged_scatter(const void* src, void* dst, const void* indices, const void* counts, long long batch,

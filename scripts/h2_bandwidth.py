@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Ragged byte movers at sizes where they are bandwidth- instead of launch-bound: achieved GB/s (algorithmic bytes =
+row read + row write per valid index, + index bytes) against torch's own gather / index_copy on the same data.
+At the sizes of the training path these ops are launch bound; this shows what the kernels do when fed."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "accv-lab_amd")]
+
+import torch  # noqa: E402
+
+from accvlab.batching_helpers import batched_indexing_access_cuda as ext  # noqa: E402
+
+
+def timeit(fn, warm=20, iters=100):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    out_lines = []
+    for (b, n, k, row) in ((64, 4096, 4096, 1024), (64, 16384, 8192, 256), (256, 900, 300, 1024), (8, 900, 100, 1024)):
+        d = row // 4
+        data = torch.randn(b, n, d, device=dev)
+        idx = torch.stack([torch.randperm(n, generator=g)[:k] for _ in range(b)]).to(dev)
+        counts = torch.randint(k // 2, k + 1, (b,), generator=g).to(dev)
+        valid = int(counts.sum())
+        out = torch.zeros(b, k, d, device=dev)
+        t_g = timeit(lambda: ext.gather_rows(data, idx, counts, k, out))
+        dst = torch.zeros(b, n, d, device=dev)
+        src = torch.randn(b, k, d, device=dev)
+        t_s = timeit(lambda: ext.scatter_rows(src, idx, counts, k, dst))
+        # torch formulations on the same (dense, all-valid) problem
+        idx_e = idx.unsqueeze(-1).expand(b, k, d)
+        t_tg = timeit(lambda: torch.gather(data, 1, idx_e, out=out))
+        t_ts = timeit(lambda: dst.scatter_(1, idx_e, src))
+        flat = torch.randn(valid, d, device=dev)
+        offs = torch.cumsum(counts, 0) - counts
+        t_p = timeit(lambda: ext.pack_rows(flat, offs, counts, k))
+        bytes_g = valid * (2 * row + 8)
+        bytes_dense = b * k * (2 * row + 8)
+        bytes_p = valid * row + b * k * row
+        out_lines.append({
+            "shape": {"batch": b, "rows": n, "indices": k, "row_bytes": row, "valid": valid},
+            "ragged_gather_GBps": bytes_g / t_g / 1e9, "ragged_scatter_GBps": bytes_g / t_s / 1e9,
+            "torch_gather_GBps": bytes_dense / t_tg / 1e9, "torch_scatter_GBps": bytes_dense / t_ts / 1e9,
+            "pack_rows_GBps": bytes_p / t_p / 1e9,
+            "us": {"gather": t_g * 1e6, "scatter": t_s * 1e6, "torch_gather": t_tg * 1e6, "torch_scatter": t_ts * 1e6,
+                   "pack": t_p * 1e6}})
+    for line in out_lines:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
