@@ -114,6 +114,23 @@ class BatchedIndexMapping(torch.autograd.Function):
         return g_src, None, None, None, g_dst
 
 
+def _run(fn, *args):
+    """``fn.apply(*args)``, or — when no argument needs a gradient — the forward alone: building an autograd node costs
+    several microseconds per call on a launch-bound path and records nothing useful then."""
+    if torch.is_grad_enabled():
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.requires_grad:
+                return fn.apply(*args)
+    return fn.forward(_NoCtx(), *args)
+
+
+class _NoCtx:
+    """Stand-in for the autograd context on the no-grad fast path."""
+
+    def save_for_backward(self, *tensors):
+        pass
+
+
 def _resolve_dim(indices: RaggedBatch, dim_to_index_in: Optional[int], what: str):
     if dim_to_index_in is None:
         dim_to_index_in = indices.non_uniform_dim
@@ -132,7 +149,7 @@ def batched_indexing_access(input_data: Union[RaggedBatch, torch.Tensor], input_
     nb = input_indices.num_batch_dims
     if swap:
         data = data.transpose(nb, dim)
-    out = BatchedIndexingAccess.apply(data, input_indices.tensor, input_indices.sample_sizes, filler_value)
+    out = _run(BatchedIndexingAccess, data, input_indices.tensor, input_indices.sample_sizes, filler_value)
     if swap:
         out = out.transpose(nb, dim)
     return input_indices.create_with_sample_sizes_like_self(out, dim)
@@ -149,7 +166,7 @@ def batched_inverse_indexing_access(input_data: Union[RaggedBatch, torch.Tensor]
     nb = output_indices.num_batch_dims
     if swap:
         data = data.transpose(nb, dim)
-    out = BatchedInverseIndexingAccessNewTensor.apply(data, output_indices.tensor, output_indices.sample_sizes,
+    out = _run(BatchedInverseIndexingAccessNewTensor, data, output_indices.tensor, output_indices.sample_sizes,
                                                       output_num_targets, filler_value)
     return out.transpose(nb, dim) if swap else out
 
@@ -167,7 +184,7 @@ def batched_indexing_write(to_write: Union[RaggedBatch, torch.Tensor], output_in
     dst = to_write_into.tensor if dst_is_rb else to_write_into
     if swap:
         src, dst = src.transpose(nb, dim), dst.transpose(nb, dim)
-    out = BatchedInverseIndexingAccessInsert.apply(src, output_indices.tensor, output_indices.sample_sizes, dst)
+    out = _run(BatchedInverseIndexingAccessInsert, src, output_indices.tensor, output_indices.sample_sizes, dst)
     if swap:
         out = out.transpose(nb, dim)
     return to_write_into.create_with_sample_sizes_like_self(out) if dst_is_rb else out
@@ -193,7 +210,7 @@ def batched_index_mapping(source_data: Union[torch.Tensor, RaggedBatch], source_
         tgt = target_data
     if isinstance(source_data, RaggedBatch):
         source_data = source_data.get_non_uniform_dimension_transposed_to(nb).tensor
-    out = BatchedIndexMapping.apply(source_data, source_indices.tensor, target_indices.tensor,
+    out = _run(BatchedIndexMapping, source_data, source_indices.tensor, target_indices.tensor,
                                     source_indices.sample_sizes, tgt)
     if tgt_is_rb:
         out = target_data.create_with_sample_sizes_like_self(out, nb)
