@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libaccv_hip.so")
 OK = 0
 HM_CLEAR = 1
 HM_COUNTS_I64 = 2
+HM_SMALL_RADII = 4
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

@@ -3,8 +3,8 @@
 EXTENSION: the reference ships no polyline rasteriser; its lane package only samples polylines
 (packages/lane_helpers/accvlab/lane_helpers/polyline/functions.py:27-111).  A lane is drawn here by composing the two
 reference operators that exist: sample every lane at ``num_samples`` arc-length-uniform positions (``interpolate`` with
-``relative=True``) and splat every sample as a Gaussian of a fixed radius (``draw_heatmap_batched``).  Three launches,
-no host synchronisation:
+``relative=True``) and splat every sample as a Gaussian of a fixed radius (``draw_heatmap_batched`` with the
+``small_radii`` hint: the splat kernel that walks each sample's few-pixel box).  Three launches, no host synchronisation:
 
     accv_polyline_sample  ->  accv_heatmap_targets_from_points_f32  ->  accv_draw_heatmap_batched_f32
 """
@@ -92,4 +92,4 @@ def draw_polylines_batched(heatmap: torch.Tensor, polylines: torch.Tensor, num_s
         sizes = num_lanes.clamp(0, l) * num_samples
     draw_heatmap_batched(heatmap, SimpleNamespace(tensor=centers, sample_sizes=sizes),
                          SimpleNamespace(tensor=radii, sample_sizes=sizes), diameter_to_sigma_factor, k_scale,
-                         clear=clear)
+                         clear=clear, small_radii=radius <= 7)

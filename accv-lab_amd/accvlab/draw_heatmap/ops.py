@@ -49,6 +49,7 @@ def draw_heatmap(
     k_scale: float = 1.0,
     *,
     clear: bool = False,
+    small_radii: bool = False,
 ) -> None:
     """Draw N Gaussians into ``heatmaps[P,H,W]`` (fp32, in place, element-wise max).
 
@@ -60,6 +61,8 @@ def draw_heatmap(
         diameter_to_sigma_factor: sigma = (2r+1) / factor.
         k_scale: peak value.
         clear: (extension) overwrite the map with max(0, splats) instead of max-ing into its content.
+        small_radii: (extension) performance hint — the radii are a few pixels (key points, lane samples; boxes up to
+            ~15x15): use the kernel that walks each object's box instead of updating whole tiles.  Same results.
 
     Reference: draw_heatmap.cpp:132-134 -> draw_heatmap_launcher (draw_heatmap_cuda.cu:62-89).
     """
@@ -92,7 +95,8 @@ def draw_heatmap(
         status = lib.accv_draw_heatmap_flat_f32(
             heatmaps.data_ptr(), planes, height, width, centers.data_ptr(), radii.data_ptr(),
             heatmap_idxes.data_ptr(), n, float(diameter_to_sigma_factor), float(k_scale),
-            _nat.HM_CLEAR if clear else 0, ws.data_ptr(), ws_bytes, _nat.stream_ptr(heatmaps.device))
+            (_nat.HM_CLEAR if clear else 0) | (_nat.HM_SMALL_RADII if small_radii else 0), ws.data_ptr(), ws_bytes,
+            _nat.stream_ptr(heatmaps.device))
         # the workspace is only used by kernels already enqueued on the current stream; the caching
         # allocator re-issues it stream-ordered, so dropping the reference here is safe
     _nat.check(status, "draw_heatmap")
@@ -107,6 +111,7 @@ def draw_heatmap_batched(
     labels=None,
     *,
     clear: bool = False,
+    small_radii: bool = False,
 ) -> None:
     """Draw a ragged batch of Gaussians (in place, element-wise max).
 
@@ -118,6 +123,7 @@ def draw_heatmap_batched(
         k_scale: peak value.
         labels: optional RaggedBatch int32 ``[B, Nmax]`` of class indices -> one plane per class.
         clear: (extension) fused zero-fill + draw in one write-only pass.
+        small_radii: (extension) performance hint for point-like objects, see :func:`draw_heatmap`.
 
     Only ``centers.sample_sizes`` decides how many leading objects of a sample are drawn; padded slots are
     never touched.  Reference: funtions/draw_heatmap_batched.py:27-84 -> draw_heatmap_batched_launcher /
@@ -183,7 +189,8 @@ def draw_heatmap_batched(
     if labels_t is not None and num_classes == 0:
         return
 
-    flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0)
+    flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0) | \
+        (_nat.HM_SMALL_RADII if small_radii else 0)
     with _nat.device_guard(heatmap.device):
         status = _nat.lib().accv_draw_heatmap_batched_f32(
             heatmap.data_ptr(), batch, num_classes, height, width, centers_t.data_ptr(), radii_t.data_ptr(),

@@ -80,6 +80,109 @@ __device__ __forceinline__ float max_skip_nan(float acc, float v)
     return r;
 }
 
+// ---------------------------------------------------------------- pieces shared by the tile kernels
+struct TileCtx {
+    int tx0, ty0, tx1, ty1;  // pixel bounds of the tile, clipped to the frame
+    long long plane;
+    const int2* centers2;    // objects of this plane: [0, n)
+    const int32_t* radii;
+    const int32_t* labels;
+    int n, cls;              // cls < 0: no class filter
+};
+
+// tile coordinates from the launch geometry + the object range that feeds this plane; false = wave has no tile
+template <int TW, int TH, int WPG>
+__device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, TileCtx& t)
+{
+    int tx, ty;
+    if (p.grid3d) {
+        // 3-D grid (x = group of WPG column tiles, y = row tile, z = plane): no divisions in the prologue
+        tx = blockIdx.x * WPG + wave;
+        ty = blockIdx.y;
+        t.plane = blockIdx.z;
+        if (tx >= p.tiles_x) return false;
+    } else {  // linear block index (more than 65535 planes or tile rows)
+        const long long tile = (long long)blockIdx.x * WPG + wave;
+        if (tile >= p.n_tiles) return false;  // whole wave exits; waves never synchronise with each other
+        tx = (int)(tile % p.tiles_x);
+        const long long t2 = tile / p.tiles_x;
+        ty = (int)(t2 % p.tiles_y);
+        t.plane = t2 / p.tiles_y;
+    }
+    t.tx0 = tx * TW;
+    t.ty0 = ty * TH;
+    t.tx1 = min(t.tx0 + TW, p.W);
+    t.ty1 = min(t.ty0 + TH, p.H);
+
+    // which objects feed this plane: objects [obj_base, obj_base + n) of centers/radii(/labels)
+    long long obj_base;
+    t.cls = -1;
+    if (p.plane_off) {  // flat API: the binning pre-pass left plane-sorted copies of the objects
+        const int o0 = p.plane_off[t.plane];
+        obj_base = o0;
+        t.n = p.plane_off[t.plane + 1] - o0;
+    } else {
+        long long s = t.plane;
+        if (p.n_classes > 0) {
+            s = t.plane / p.n_classes;
+            t.cls = (int)(t.plane - s * p.n_classes);
+        }
+        long long cnt = p.counts_i64 ? ((const long long*)p.counts)[s] : (long long)((const int*)p.counts)[s];
+        t.n = (int)max(0ll, min(cnt, (long long)p.n_max));
+        obj_base = s * p.n_max;
+    }
+    t.centers2 = reinterpret_cast<const int2*>(p.centers) + obj_base;
+    t.radii = p.radii + obj_base;
+    t.labels = p.labels + obj_base;
+    return true;
+}
+
+// One candidate per lane and round, fetched with branch-free loads (index clamped to the last object, result masked).
+// The cull is VALU-bound for long object lists (lane rasters walk 10^3 candidates per tile), so the test every lane
+// runs is a cheap CONSERVATIVE one in 32-bit: coordinates clamped to +-2^29 and the radius to 2^30 cannot overflow and
+// never miss a real hit while H, W <= 2^29 (host-checked).  Returns the ballot of hitting lanes.
+struct Cand {
+    int x, y, r, label;
+};
+__device__ __forceinline__ Cand cull_load(const TileCtx& t, int base, int lane)
+{
+    const int cc = min(base + lane, t.n - 1);  // n >= 1 inside the candidate loop
+    const int2 cxy = t.centers2[cc];
+    return Cand{cxy.x, cxy.y, t.radii[cc], t.labels[cc]};
+}
+__device__ __forceinline__ unsigned long long cull_test(const TileCtx& t, int base, int lane, const Cand& c)
+{
+    constexpr int kClampXY = 1 << 29, kClampR = 1 << 30;
+    const int xc = min(max(c.x, -kClampXY), kClampXY), yc = min(max(c.y, -kClampXY), kClampXY);
+    const int rc = min(c.r, kClampR);
+    const bool hit = (base + lane < t.n) && (t.cls < 0 || c.label == t.cls) && c.r >= 0 && xc - rc < t.tx1 &&
+                     xc + rc >= t.tx0 && yc - rc < t.ty1 && yc + rc >= t.ty0;
+    return __ballot(hit);
+}
+__device__ __forceinline__ unsigned long long cull_round(const TileCtx& t, int base, int lane, int& x, int& y, int& r)
+{
+    const Cand c = cull_load(t, base, lane);
+    x = c.x;
+    y = c.y;
+    r = c.r;
+    return cull_test(t, base, lane, c);
+}
+
+// hit record of a lane that passed the cull: the exact clipped box of the reference (left/right/top/bottom,
+// cuh:64-67, 92-95; 64-bit), relative to the tile and clamped to it; an empty exact box masks every pixel
+__device__ __forceinline__ Hit make_hit(const SplatParams& p, const TileCtx& t, int x, int y, int r)
+{
+    const float sigma = (float)(2 * r + 1) / p.factor;
+    const float c2 = kLog2e / (2.0f * sigma * sigma);
+    const long long x0 = (long long)x - min(x, r), x1 = (long long)x + min((long long)p.W - x, (long long)r + 1);
+    const long long y0 = (long long)y - min(y, r), y1 = (long long)y + min((long long)p.H - y, (long long)r + 1);
+    const long long xlo = max(x0, (long long)t.tx0) - t.tx0, xhi = min(x1, (long long)t.tx1) - t.tx0;
+    const long long ylo = max(y0, (long long)t.ty0) - t.ty0, yhi = min(y1, (long long)t.ty1) - t.ty0;
+    unsigned box = 0;  // empty: only possible for coordinates beyond the clamps of the cull
+    if (xhi > xlo && yhi > ylo) box = (unsigned)xlo | ((unsigned)xhi << 8) | ((unsigned)ylo << 16) | ((unsigned)yhi << 24);
+    return Hit{x, y, c2, box};
+}
+
 template <int PX, int R, bool CLEAR, int SM, int WPG = kWavesPerGroup>
 __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
 {
@@ -93,43 +196,10 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int tx, ty;
-    long long plane;
-    if (p.grid3d) {
-        // 3-D grid (x = group of WPG column tiles, y = row tile, z = plane): no divisions in the prologue
-        tx = blockIdx.x * kWavesPerGroup + wave;
-        ty = blockIdx.y;
-        plane = blockIdx.z;
-        if (tx >= p.tiles_x) return;
-    } else {  // linear block index (more than 65535 planes or tile rows)
-        const long long tile = (long long)blockIdx.x * kWavesPerGroup + wave;
-        if (tile >= p.n_tiles) return;  // whole wave exits; waves never synchronise with each other
-        tx = (int)(tile % p.tiles_x);
-        const long long t2 = tile / p.tiles_x;
-        ty = (int)(t2 % p.tiles_y);
-        plane = t2 / p.tiles_y;
-    }
-
-    const int tx0 = tx * TW, ty0 = ty * TH;
-    const int tx1 = min(tx0 + TW, p.W), ty1 = min(ty0 + TH, p.H);
-
-    // which objects feed this plane: objects [obj_base, obj_base + n) of centers/radii(/labels)
-    long long obj_base;
-    int n, cls = -1;
-    if (p.plane_off) {  // flat API: the binning pre-pass left plane-sorted copies of the objects
-        const int o0 = p.plane_off[plane];
-        obj_base = o0;
-        n = p.plane_off[plane + 1] - o0;
-    } else {
-        long long s = plane;
-        if (p.n_classes > 0) {
-            s = plane / p.n_classes;
-            cls = (int)(plane - s * p.n_classes);
-        }
-        long long cnt = p.counts_i64 ? ((const long long*)p.counts)[s] : (long long)((const int*)p.counts)[s];
-        n = (int)max(0ll, min(cnt, (long long)p.n_max));
-        obj_base = s * p.n_max;
-    }
+    TileCtx t;
+    if (!locate_tile<TW, TH, kWavesPerGroup>(p, wave, t)) return;
+    const int tx0 = t.tx0, ty0 = t.ty0, n = t.n;
+    const long long plane = t.plane;
 
     const int sub = lane >> 5;  // which half-wave: rows [sub*R, sub*R + R) of the tile
     const int col0 = tx0 + (lane & 31) * PX;
@@ -143,28 +213,11 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
 
     int total_hits = 0;
 
-    // One candidate per lane and round, fetched with branch-free loads (index clamped to the last object, result
-    // masked).  The cull is VALU-bound for long object lists (lane rasters walk 10^3 candidates per tile), so the test
-    // every lane runs is a cheap CONSERVATIVE one in 32-bit: coordinates clamped to +-2^29 and the radius to 2^30
-    // cannot overflow and never miss a real hit while H, W <= 2^29 (host-checked); the exact clipped box of the
-    // reference (64-bit) is only computed for lanes that hit, and an empty exact box simply masks every pixel.
-    const int2* __restrict__ centers2 = reinterpret_cast<const int2*>(p.centers) + obj_base;
-    const int32_t* __restrict__ radii = p.radii + obj_base;
-    const int32_t* __restrict__ labels = p.labels + obj_base;
-    constexpr int kClampXY = 1 << 29, kClampR = 1 << 30;
-
     for (int base = 0; base < n; base += kCand) {
-        // ---- cull: ballot, popcount-prefix compaction into LDS
-        const int cc = min(base + lane, n - 1);
-        const int2 cxy = centers2[cc];
-        const int x = cxy.x, y = cxy.y, r = radii[cc];
-        const int label = labels[cc];
-        const int xc = min(max(x, -kClampXY), kClampXY), yc = min(max(y, -kClampXY), kClampXY);
-        const int rc = min(r, kClampR);
-        const bool hit = (base + lane < n) && (cls < 0 || label == cls) && r >= 0 && xc - rc < tx1 && xc + rc >= tx0 &&
-                         yc - rc < ty1 && yc + rc >= ty0;
-
-        const unsigned long long m = __ballot(hit);
+        // ---- cull: conservative 32-bit test, ballot, popcount-prefix compaction into LDS
+        int x, y, r;
+        const unsigned long long m = cull_round(t, base, lane, x, y, r);
+        const bool hit = (m >> lane) & 1ull;
         const int nh = __popcll(m);
         if (nh == 0) continue;
         if constexpr (!CLEAR) {
@@ -189,21 +242,7 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
                 }
             }
         }
-        if (hit) {
-            const int pos = __popcll(m & ((1ull << lane) - 1ull));
-            const float sigma = (float)(2 * r + 1) / p.factor;
-            const float c2 = kLog2e / (2.0f * sigma * sigma);
-            // clipped box, exactly the reference's left/right/top/bottom (cuh:64-67, 92-95), in 64-bit, then relative
-            // to the tile and clamped to it
-            const long long x0 = (long long)x - min(x, r), x1 = (long long)x + min((long long)p.W - x, (long long)r + 1);
-            const long long y0 = (long long)y - min(y, r), y1 = (long long)y + min((long long)p.H - y, (long long)r + 1);
-            const long long xlo = max(x0, (long long)tx0) - tx0, xhi = min(x1, (long long)tx1) - tx0;
-            const long long ylo = max(y0, (long long)ty0) - ty0, yhi = min(y1, (long long)ty1) - ty0;
-            unsigned box = 0;  // empty: only possible for coordinates beyond the clamps above
-            if (xhi > xlo && yhi > ylo)
-                box = (unsigned)xlo | ((unsigned)xhi << 8) | ((unsigned)ylo << 16) | ((unsigned)yhi << 24);
-            s_hit[wave][pos] = Hit{x, y, c2, box};
-        }
+        if (hit) s_hit[wave][__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, x, y, r);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
@@ -273,6 +312,137 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
             *dst = out;
         }
     }
+}
+
+// ---------------------------------------------------------------- small splats (lane rasters, point-like targets)
+// The tile kernel above pays a full 128x16-pixel register update per hit, whatever the size of the object's box.  For
+// boxes of a few pixels (a lane sample of radius 2 covers 5x5) that is 2048 pixel updates for 25 useful ones, and
+// tiles that a lane crosses hold 10^2 such hits.  This variant keeps the tile in LDS instead (8 KB per wave) and, per
+// hit, lets 16 lanes walk the pixels of the hit's clipped box only: v = k * exp2(-(dx^2 + dy^2) c), one LDS float-max
+// atomic (ds_max_f32) per box pixel, four hits in flight per wave.  Correct for any radius, but only faster below ~15x15 boxes; the host selects it on the
+// caller's ACCV_HM_SMALL_RADII hint.  Same culling, same store path, same clear / in-place semantics.
+template <bool CLEAR, int SM>
+__global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
+{
+    constexpr int TW = 128, TH = 16;
+    __shared__ Hit s_hit[kCand];
+    __shared__ __attribute__((aligned(16))) float s_tile[TH][TW];
+
+    const int lane = threadIdx.x & 63;
+    TileCtx t;
+    if (!locate_tile<TW, TH, 1>(p, 0, t)) return;
+    const int sub = lane >> 5, col0 = t.tx0 + (lane & 31) * 4;
+
+    // "untouched" is -inf in the LDS tile (fused-clear mode starts from 0 = the cleared map)
+    const float init = CLEAR ? 0.0f : -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<vfloat4*>(&s_tile[sub * 8 + i][(lane & 31) * 4]) = vfloat4{init, init, init, init};
+
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile initialised before the first atomic
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // long object lists are the normal case here (10^3 lane samples per plane) and the wave needs few registers, so
+    // the candidate loads of kFetch rounds are issued together: one memory round trip per kFetch * 64 candidates
+    constexpr int kFetch = 4;
+    int total_hits = 0;
+    for (int base = 0; base < t.n; base += kFetch * kCand) {
+        Cand cand[kFetch];
+#pragma unroll
+        for (int u = 0; u < kFetch; ++u) cand[u] = cull_load(t, base + u * kCand, lane);
+#pragma unroll
+        for (int u = 0; u < kFetch; ++u) {
+            const int sub_base = base + u * kCand;
+            if (sub_base >= t.n) break;
+            const unsigned long long m = cull_test(t, sub_base, lane, cand[u]);
+            const int nh = __popcll(m);
+            if (nh == 0) continue;
+            if ((m >> lane) & 1ull)
+                s_hit[__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, cand[u].x, cand[u].y, cand[u].r);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // four hits at a time, 16 lanes per hit walking its box.  Pixel updates are LDS float-max atomics
+            // (ds_max_f32, no return value): they commute, so neither overlapping boxes of concurrent hits nor
+            // successive hits need any ordering — the wave just streams them
+            const int grp = lane >> 4, l16 = lane & 15;
+            for (int h0 = 0; h0 < nh; h0 += 4) {
+                const int h = h0 + grp;
+                if (h >= nh) continue;
+                const Hit hh = s_hit[h];
+                const int xlo = hh.box & 255u, xhi = (hh.box >> 8) & 255u, ylo = (hh.box >> 16) & 255u, yhi = hh.box >> 24;
+                const int w = xhi - xlo, area = w * (yhi - ylo);  // 0 for an empty box
+                const float inv_w = 1.0f / (float)max(w, 1);
+                for (int q = l16; q < area; q += 16) {
+                    // q / w for q < 2048, w <= 128: (q + 0.5) / w is at least 1/256 away from an integer, far more
+                    // than the error of the reciprocal
+                    const int py = (int)(((float)q + 0.5f) * inv_w);
+                    const int px = q - py * w;
+                    const float dx = (float)(t.tx0 + xlo + px - hh.x), dy = (float)(t.ty0 + ylo + py - hh.y);
+                    const float v = p.k * raw_exp2(-(dx * dx + dy * dy) * hh.c2);
+                    __hip_atomic_fetch_max(&s_tile[ylo + py][xlo + px], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+            // the next sub-round overwrites the hit list: order it behind this round's reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            total_hits += nh;
+        }
+    }
+
+    if (!CLEAR && total_hits == 0) return;  // in-place: untouched tile costs no HBM traffic
+    if (col0 >= p.W) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // all atomics landed before the tile is read back
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* plane_ptr = p.hm + (size_t)t.plane * (size_t)p.H * (size_t)p.W;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = t.ty0 + sub * 8 + i;
+        if (row >= p.H) break;
+        vfloat4 out = *reinterpret_cast<const vfloat4*>(&s_tile[sub * 8 + i][(lane & 31) * 4]);
+        vfloat4* dst = reinterpret_cast<vfloat4*>(plane_ptr + (size_t)row * p.W + col0);
+        if constexpr (!CLEAR) {
+            const vfloat4 old = *dst;
+            const float nanv = __builtin_nanf("");
+            out.x = max_skip_nan(old.x, out.x == init ? nanv : out.x);
+            out.y = max_skip_nan(old.y, out.y == init ? nanv : out.y);
+            out.z = max_skip_nan(old.z, out.z == init ? nanv : out.z);
+            out.w = max_skip_nan(old.w, out.w == init ? nanv : out.w);
+        }
+        if constexpr (SM >= 2) {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(out, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, 18);
+        } else {
+            *dst = out;
+        }
+    }
+}
+
+int launch_splat_small(SplatParams p, long long planes, bool clear, int sm, hipStream_t stream)
+{
+    p.tiles_x = (p.W + 127) / 128;
+    p.tiles_y = (p.H + 15) / 16;
+    p.n_tiles = planes * p.tiles_x * p.tiles_y;
+    if (p.n_tiles == 0) return ACCV_OK;
+    dim3 grid;
+    p.grid3d = (planes <= 65535 && p.tiles_y <= 65535) ? 1 : 0;
+    if (p.grid3d) {
+        grid = dim3((unsigned)p.tiles_x, (unsigned)p.tiles_y, (unsigned)planes);
+    } else {
+        if (p.n_tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap: %lld tiles exceed the grid limit", p.n_tiles);
+        grid = dim3((unsigned)p.n_tiles);
+    }
+    if (clear) {
+        if (sm >= 2)
+            hipLaunchKernelGGL((splat_small_kernel<true, 4>), grid, dim3(64), 0, stream, p);
+        else
+            hipLaunchKernelGGL((splat_small_kernel<true, 0>), grid, dim3(64), 0, stream, p);
+    } else {
+        if (sm >= 2)
+            hipLaunchKernelGGL((splat_small_kernel<false, 4>), grid, dim3(64), 0, stream, p);
+        else
+            hipLaunchKernelGGL((splat_small_kernel<false, 0>), grid, dim3(64), 0, stream, p);
+    }
+    return accv::check_launch("draw_heatmap small-splat kernel");
 }
 
 // ---------------------------------------------------------------- target-prep front end
@@ -414,7 +584,7 @@ int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_
     return accv::check_launch("draw_heatmap splat kernel");
 }
 
-int dispatch_splat(SplatParams p, long long planes, bool clear, hipStream_t stream)
+int dispatch_splat(SplatParams p, long long planes, bool clear, bool small_hint, hipStream_t stream)
 {
     const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.hm) & 15u) == 0);
     // store policy: outputs far larger than L2 + Infinity Cache stream straight to HBM with write-through,
@@ -428,6 +598,9 @@ int dispatch_splat(SplatParams p, long long planes, bool clear, hipStream_t stre
     // tuning knobs exist for in-process A/B runs (scripts/h1_variants.py); the defaults are the shipped configuration
     if (!p.labels) p.labels = p.radii;  // branch-free candidate loads: always a readable array (ignored when cls < 0)
     if (!vec4) return launch_splat<1, 8>(p, planes, clear, 0, stream);
+    // point-like objects (caller's ACCV_HM_SMALL_RADII hint; "hm_small" 0/1 overrides for tests and A/B runs)
+    const int small = accv::tune_get("hm_small", -1);
+    if (small > 0 || (small < 0 && small_hint)) return launch_splat_small(p, planes, clear, nt, stream);
     const int wpg = accv::tune_get("hm_wpg", kWavesPerGroup);
     if (accv::tune_get("hm_rows", 8) == 16) return launch_splat<4, 16>(p, planes, clear, nt, stream);
     if (wpg == 4) return launch_splat<4, 8, 4>(p, planes, clear, nt, stream);
@@ -502,7 +675,7 @@ int accv_draw_heatmap_flat_f32(float* heatmaps, int num_planes, int height, int 
     p.W = width;
     p.factor = diameter_to_sigma_factor;
     p.k = k_scale;
-    return dispatch_splat(p, num_planes, clear, stream);
+    return dispatch_splat(p, num_planes, clear, (flags & ACCV_HM_SMALL_RADII) != 0, stream);
 }
 
 int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, int height, int width,
@@ -540,7 +713,7 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
     p.k = k_scale;
     p.counts_i64 = (flags & ACCV_HM_COUNTS_I64) ? 1 : 0;
     const long long planes = (long long)batch * (num_classes > 0 ? num_classes : 1);
-    return dispatch_splat(p, planes, clear, stream);
+    return dispatch_splat(p, planes, clear, (flags & ACCV_HM_SMALL_RADII) != 0, stream);
 }
 
 int accv_heatmap_targets_from_boxes_f32(const float* centers_xy, const float* boxes_xyxy, long long num_objects,

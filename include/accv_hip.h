@@ -31,6 +31,9 @@ extern "C" {
 /* flags for the draw_heatmap entry points */
 #define ACCV_HM_CLEAR 1u       /* fused clear: result = max(0, splats); every pixel is written exactly once */
 #define ACCV_HM_COUNTS_I64 2u  /* `counts` points to int64 (RaggedBatch.sample_sizes) instead of int32 */
+#define ACCV_HM_SMALL_RADII 4u /* hint: radii of a few pixels (lane samples, key points; boxes up to ~15x15): take the
+                                 kernel that walks each object's box instead of updating whole tiles.  Results do
+                                 not depend on the hint; objects of any size stay correct, only slower. */
 
 const char* accv_last_error(void);
 int accv_version(void);

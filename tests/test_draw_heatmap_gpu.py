@@ -22,14 +22,14 @@ def rb(t, sizes):
     return SimpleNamespace(tensor=t, sample_sizes=sizes)
 
 
-_VARIANTS = {"shipped": {}, "rows16": {"hm_rows": 16}, "wpg4": {"hm_wpg": 4}}
-_DEFAULTS = {"hm_rows": 8, "hm_wpg": 1}
+_VARIANTS = {"shipped": {}, "rows16": {"hm_rows": 16}, "wpg4": {"hm_wpg": 4}, "small-splat": {"hm_small": 1}}
+_DEFAULTS = {"hm_rows": 8, "hm_wpg": 1, "hm_small": -1}
 
 
 @pytest.fixture(autouse=True, params=list(_VARIANTS), ids=list(_VARIANTS))
 def kernel_variant(request):
     """every test of this module runs against the shipped splat-kernel instantiation and the alternative ones that
-    the tune knobs can select (tile rows, waves per workgroup)"""
+    the tune knobs can select (tile rows, waves per workgroup, the box-walking small-splat kernel)"""
     from accvlab import _amd_native as nat
 
     for k, v in _VARIANTS[request.param].items():
