@@ -17,6 +17,11 @@ import torch
 from . import batched_indexing_access_cuda as _ext
 from .ragged import RaggedBatch
 
+try:  # C++ per-sample loops (built by `make -C accv-lab_amd/csrc_host`); the python code below is the fallback
+    from . import _bh_host as _bh
+except ImportError:  # pragma: no cover
+    _bh = None
+
 
 # ------------------------------------------------------------------------------------------ reductions
 def sum_over_targets(data: RaggedBatch) -> torch.Tensor:
@@ -157,6 +162,17 @@ def combine_data(data_list: Sequence[Union[Sequence, torch.Tensor]], other_with_
     share = other_with_same_sample_sizes
 
     if flatten_batch_dims:
+        if _bh is not None and (device is None or torch.device(device).type == "cpu"):
+            fast = _bh.pack_cpu(data_list)      # C++ loop; declines (None) for anything but plain CPU tensors
+            if fast is not None:
+                padded, sizes_cpu = fast
+                if share is None:
+                    return RaggedBatch(padded, sample_sizes=sizes_cpu)
+                assert padded.shape[0] == share.sample_sizes.shape[0], \
+                    "Number of samples does not match `other_with_same_sample_sizes`"
+                assert tuple(padded.shape[:2]) == tuple(share.mask.shape), \
+                    "Needed mask dimension does not match `other_with_same_sample_sizes`"
+                return share.create_with_sample_sizes_like_self(padded, non_uniform_dim=1, device=padded.device)
         leaves: List[torch.Tensor] = []
         _walk_flat(data_list, leaves)
         if not leaves:

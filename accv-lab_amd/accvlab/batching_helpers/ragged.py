@@ -26,6 +26,12 @@ def _as_tuple(shape) -> Tuple[int, ...]:
     return (int(shape),) if isinstance(shape, int) else tuple(int(s) for s in shape)
 
 
+try:  # C++ per-sample loops (built by `make -C accv-lab_amd/csrc_host`)
+    from . import _bh_host as _bh
+except ImportError:  # pragma: no cover
+    _bh = None
+
+
 class RaggedBatch:
     """Batch whose samples differ in size along one ("non-uniform") dimension.
 
@@ -406,11 +412,14 @@ class RaggedBatch:
         flat = data.reshape(-1, *data.shape[nb:]) if nb > 1 else data
         width = flat.shape[1] if flat.dim() > 1 else 0
 
-        leaves = []
-        for s, n in zip(flat.unbind(0), sizes):     # one C++ call for the per-sample views, one narrow each
-            if n != width:
-                s = s.narrow(0, 0, n)
-            leaves.append(s.transpose(0, back) if back else s)
+        if _bh is not None and flat.dim() > 1:
+            leaves = _bh.split_views(flat, sizes, back)   # the per-sample view loop in C++
+        else:
+            leaves = []
+            for s, n in zip(flat.unbind(0), sizes):
+                if n != width:
+                    s = s.narrow(0, 0, n)
+                leaves.append(s.transpose(0, back) if back else s)
 
         def nest(items, shape):
             if len(shape) == 1:

@@ -1,0 +1,126 @@
+// Host-side fast path of accvlab.batching_helpers for the per-sample python loops of the reference
+// (combine_data: one slice-assign per sample, batched_processing_py.py:410-427; RaggedBatch.split: one view per sample,
+// ragged_batch.py:870-934): the same loops in C++ over ATen, so a 64-sample pack / split costs one python call.
+// Plumbing only — no device code, no HIP calls.  Anything unusual (mixed devices or dtypes, gradients, non-tensor
+// leaves) makes these functions decline (return None), and the python implementation handles it and raises the
+// reference's error messages.
+#include <torch/extension.h>
+
+#include <cstring>
+#include <vector>
+
+namespace py = pybind11;
+
+namespace {
+
+// depth-first flatten of nested list/tuple structures into tensor leaves; false = something else was found
+bool flatten(PyObject* obj, std::vector<at::Tensor>& out)
+{
+    if (THPVariable_Check(obj)) {
+        out.push_back(THPVariable_Unpack(obj));
+        return true;
+    }
+    if (PyList_CheckExact(obj)) {
+        const Py_ssize_t n = PyList_GET_SIZE(obj);
+        for (Py_ssize_t i = 0; i < n; ++i)
+            if (!flatten(PyList_GET_ITEM(obj, i), out)) return false;
+        return true;
+    }
+    if (PyTuple_CheckExact(obj)) {
+        const Py_ssize_t n = PyTuple_GET_SIZE(obj);
+        for (Py_ssize_t i = 0; i < n; ++i)
+            if (!flatten(PyTuple_GET_ITEM(obj, i), out)) return false;
+        return true;
+    }
+    return false;
+}
+
+// combine_data, flatten mode, CPU target: (padded [B, width, *inner], sizes int64 [B]) or None
+py::object pack_cpu(const py::object& data)
+{
+    std::vector<at::Tensor> leaves;
+    if (!flatten(data.ptr(), leaves) || leaves.empty()) return py::none();
+    const at::Tensor* proto = nullptr;
+    int64_t width = 0;
+    for (const auto& t : leaves) {
+        if (!t.defined() || !t.device().is_cpu() || t.requires_grad() || t.dim() < 1 || t.is_sparse() || t.is_quantized())
+            return py::none();
+        width = std::max<int64_t>(width, t.size(0));
+        if (!proto && t.numel() > 0) proto = &t;
+    }
+    if (!proto) return py::none();  // nothing but empty samples: rare, python handles it
+    const auto inner = proto->sizes().slice(1);
+    for (const auto& t : leaves) {
+        if (t.numel() == 0) continue;
+        if (t.scalar_type() != proto->scalar_type() || t.sizes().slice(1) != inner) return py::none();
+    }
+    const int64_t b = (int64_t)leaves.size();
+    std::vector<int64_t> shape{b, width};
+    shape.insert(shape.end(), inner.begin(), inner.end());
+    at::Tensor padded = at::zeros(shape, proto->options());
+    at::Tensor sizes = at::empty({b}, at::TensorOptions().dtype(at::kLong));
+    int64_t* sz = sizes.data_ptr<int64_t>();
+    int64_t row_elems = 1;
+    for (auto s : inner) row_elems *= s;
+    const size_t row_bytes = (size_t)row_elems * proto->element_size();
+    char* base = static_cast<char*>(padded.data_ptr());
+    for (int64_t i = 0; i < b; ++i) {
+        const at::Tensor& t = leaves[(size_t)i];
+        const int64_t n = t.numel() == 0 ? 0 : t.size(0);
+        sz[i] = n;
+        if (n == 0) continue;
+        char* dst = base + (size_t)i * (size_t)width * row_bytes;
+        if (t.is_contiguous()) {
+            std::memcpy(dst, t.data_ptr(), (size_t)n * row_bytes);
+        } else {
+            padded.select(0, i).narrow(0, 0, n).copy_(t);
+        }
+    }
+    return py::make_tuple(padded, sizes);
+}
+
+// RaggedBatch.split for one (flattened) batch dimension: views flat[i].narrow(0, 0, sizes[i]) (+ transpose(0, back))
+std::vector<at::Tensor> split_views(const at::Tensor& flat, const std::vector<int64_t>& sizes, int64_t back)
+{
+    TORCH_CHECK(flat.dim() >= 2, "split_views needs [batch, width, ...]");
+    TORCH_CHECK((int64_t)sizes.size() == flat.size(0), "one size per sample expected");
+    const int64_t width = flat.size(1);
+    std::vector<at::Tensor> out;
+    out.reserve(sizes.size());
+    // tensors outside autograd: build each view's TensorImpl directly on the storage (no dispatcher round trips);
+    // tensors that require grad keep the differentiable select/narrow views
+    const bool direct = !flat.requires_grad() && !flat.is_sparse() && flat.has_storage() && !flat.is_inference();
+    std::vector<int64_t> vsizes(flat.sizes().begin() + 1, flat.sizes().end());
+    std::vector<int64_t> vstrides(flat.strides().begin() + 1, flat.strides().end());
+    if (direct && back) {
+        TORCH_CHECK(back < (int64_t)vsizes.size(), "dimension out of range");
+        std::swap(vstrides[0], vstrides[(size_t)back]);
+    }
+    for (int64_t i = 0; i < (int64_t)sizes.size(); ++i) {
+        const int64_t n = sizes[(size_t)i];
+        TORCH_CHECK(n >= 0 && n <= width, "sample size ", n, " outside [0, ", width, "]");
+        if (direct) {
+            auto impl = c10::make_intrusive<at::TensorImpl>(c10::Storage(flat.storage()), flat.key_set(), flat.dtype());
+            std::vector<int64_t> sz = vsizes;
+            sz[0] = n;                                  // the ragged dimension (dim 0 of the sample)
+            if (back) std::swap(sz[0], sz[(size_t)back]);
+            impl->set_sizes_and_strides(sz, vstrides);
+            impl->set_storage_offset(flat.storage_offset() + i * flat.stride(0));
+            out.emplace_back(std::move(impl));
+            continue;
+        }
+        at::Tensor s = flat.select(0, i);
+        if (n != width) s = s.narrow(0, 0, n);
+        out.push_back(back ? s.transpose(0, back) : s);
+    }
+    return out;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "host fast path of accvlab.batching_helpers (per-sample pack / split loops)";
+    m.def("pack_cpu", &pack_cpu);
+    m.def("split_views", &split_views);
+}

@@ -1,0 +1,116 @@
+"""The C++ per-sample loops of batching_helpers (csrc_host/bh_host.cpp: combine_data pack, RaggedBatch.split views)
+must be indistinguishable from the python implementation they shortcut (which mirrors
+batched_processing_py.py:410-427 and ragged_batch.py:870-934 of the reference)."""
+import pytest
+import torch
+
+from accvlab.batching_helpers import RaggedBatch, combine_data, packing, ragged
+
+
+def _both(fn):
+    """run fn with the C++ loops and with the python fallback"""
+    assert packing._bh is not None and ragged._bh is not None, "the batching_helpers host extension was not built"
+    fast = fn()
+    saved = packing._bh, ragged._bh
+    packing._bh = ragged._bh = None
+    try:
+        slow = fn()
+    finally:
+        packing._bh, ragged._bh = saved
+    return fast, slow
+
+
+def _same_rb(a: RaggedBatch, b: RaggedBatch):
+    assert a.tensor.dtype == b.tensor.dtype and a.tensor.shape == b.tensor.shape
+    assert torch.equal(a.tensor, b.tensor)
+    assert torch.equal(a.sample_sizes, b.sample_sizes) and a.sample_sizes.dtype == b.sample_sizes.dtype
+    assert torch.equal(a.mask, b.mask)
+    assert a.non_uniform_dim == b.non_uniform_dim and a.num_batch_dims == b.num_batch_dims
+
+
+def _samples(seed, n=17, inner=(4,), dtype=torch.float32, with_empty=True):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n):
+        k = int(torch.randint(0 if with_empty else 1, 9, (1,), generator=g))
+        out.append((torch.randn(k, *inner, generator=g) * 10).to(dtype))
+    return out
+
+
+@pytest.mark.parametrize("inner,dtype", [((4,), torch.float32), ((), torch.int64), ((2, 3), torch.float64),
+                                         ((5,), torch.float16), ((1,), torch.bool)])
+def test_pack_matches_python(inner, dtype):
+    data = _samples(1, inner=inner, dtype=dtype)
+    fast, slow = _both(lambda: combine_data(data))
+    _same_rb(fast, slow)
+
+
+def test_pack_nested_tuple_noncontiguous_and_shared_sizes():
+    data = _samples(2, n=12, inner=(6,), with_empty=False)
+    data[3] = data[3][:, ::2].repeat(1, 2)[:, ::1].t().contiguous().t()      # non-contiguous leaf, same shape
+    assert not data[3].is_contiguous()
+    nested = [tuple(data[:5]), [data[5:9], (data[9], data[10])], data[11]]
+    fast, slow = _both(lambda: combine_data(nested))
+    _same_rb(fast, slow)
+    other = combine_data([torch.zeros(t.shape[0], 2) for t in data])
+    fast, slow = _both(lambda: combine_data(nested, other_with_same_sample_sizes=other))
+    _same_rb(fast, slow)
+    assert fast.sample_sizes is other.sample_sizes or torch.equal(fast.sample_sizes, other.sample_sizes)
+
+
+def test_cases_the_cpp_path_declines_still_work():
+    # mixed dtypes (converted to the first non-empty sample's dtype), gradients, a device argument, all-empty input
+    mixed = [torch.ones(2, 3), torch.ones(1, 3, dtype=torch.float64)]
+    fast, slow = _both(lambda: combine_data(mixed))
+    _same_rb(fast, slow)
+    leaf = torch.ones(2, 3, requires_grad=True)
+    rb = combine_data([leaf, torch.zeros(1, 3)])
+    assert rb.tensor.requires_grad
+    rb.tensor.sum().backward()
+    assert torch.equal(leaf.grad, torch.ones(2, 3))
+    fast, slow = _both(lambda: combine_data(_samples(3), device="cpu"))
+    _same_rb(fast, slow)
+    fast, slow = _both(lambda: combine_data([torch.zeros(0, 4), torch.zeros(0, 4)]))
+    _same_rb(fast, slow)
+    with pytest.raises(AssertionError):
+        combine_data([torch.zeros(1, 2), "not a tensor"])
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("nested_batch", [False, True])
+def test_split_matches_python(transposed, nested_batch):
+    g = torch.Generator().manual_seed(5)
+    if nested_batch:
+        t = torch.randn(2, 3, 7, 4, generator=g)
+        sizes = torch.randint(0, 8, (2, 3), generator=g)
+        rb = RaggedBatch(t, sample_sizes=sizes, non_uniform_dim=2)
+    else:
+        t = torch.randn(6, 7, 4, generator=g)
+        rb = RaggedBatch(t, sample_sizes=torch.randint(0, 8, (6,), generator=g))
+    if transposed:
+        rb = rb.get_non_uniform_dimension_transposed_to(rb.non_uniform_dim + 1)
+
+    def flat(x):
+        return [x] if isinstance(x, torch.Tensor) else [y for el in x for y in flat(el)]
+
+    fast, slow = _both(lambda: rb.split())
+    ff, fs = flat(fast), flat(slow)
+    assert len(ff) == len(fs) == rb.sample_sizes.numel()
+    for a, b in zip(ff, fs):
+        assert a.shape == b.shape and a.stride() == b.stride() and torch.equal(a, b)
+        assert a.data_ptr() == b.data_ptr()                    # both are views of the batch tensor
+    # writes through a split view land in the batch tensor
+    if ff[0].numel():
+        ff[0].fill_(123.0)
+        assert (rb.tensor == 123.0).any()
+
+
+def test_split_of_a_tensor_that_requires_grad_stays_differentiable():
+    t = torch.randn(3, 5, 2, requires_grad=True)
+    rb = RaggedBatch(t * 1.0, sample_sizes=torch.tensor([5, 2, 0]))
+    parts = rb.split()
+    (parts[0].sum() + 2 * parts[1].sum()).backward()
+    want = torch.zeros(3, 5, 2)
+    want[0] = 1.0
+    want[1, :2] = 2.0
+    assert torch.equal(t.grad, want)
