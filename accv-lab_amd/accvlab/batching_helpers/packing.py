@@ -148,6 +148,47 @@ def _build_padded(leaves: List[torch.Tensor], lens: List[int], width: int, proto
     return padded.view((b, width) + inner), sizes_cpu
 
 
+_DIRECT_PADDED_BYTES = 1 << 20
+
+
+def _fast_pack(data_list, device):
+    """combine_data (flatten mode) through the C++ loops of _bh_host; None = not a plain case, use the python path.
+    Returns (padded on the target device, int64 sizes on the target device)."""
+    target = None if device is None else torch.device(device)
+    if target is None or target.type == "cpu":
+        fast = _bh.pack_cpu(data_list, False)     # declines unless every sample is a plain CPU tensor
+        if fast is not None:
+            return fast
+        if target is not None:
+            return None
+    if target is not None and target.type != "cuda":
+        return None
+    first = data_list[0]
+    while _is_seq(first) and len(first):
+        first = first[0]
+    if not isinstance(first, torch.Tensor):
+        return None
+    if first.device.type == "cpu":
+        if target is None:
+            return None
+        # CPU samples -> GPU: small batches travel PADDED (pinned, one asynchronous copy, no kernel at all)
+        # (bigger batches: flat transfer + pack kernel on the python path, so that the padding never crosses the link)
+        small = _bh.pack_cpu(data_list, True, _DIRECT_PADDED_BYTES)
+        if small is None:
+            return None
+        return small[0].to(target, non_blocking=True), small[1].to(target, non_blocking=True)
+    if first.device.type != "cuda" or (target is not None and target != first.device):
+        return None
+    got = _bh.cat_leaves(data_list, True)         # GPU samples: trim/check loop + cat in C++, then the pack kernel
+    if got is None:
+        return None
+    flat, sizes_cpu, meta, width = got
+    if flat.numel() == 0 or width == 0:
+        return None
+    meta_dev = meta.to(flat.device, non_blocking=True)
+    return _ext.pack_rows(flat, meta_dev[0], meta_dev[1], width), meta_dev[1]
+
+
 def combine_data(data_list: Sequence[Union[Sequence, torch.Tensor]], other_with_same_sample_sizes: RaggedBatch = None,
                  device: Optional[Union[torch.device, str]] = None, flatten_batch_dims: bool = True) -> RaggedBatch:
     """Pack a (nested) sequence of per-sample tensors ``(n_i, *d)`` into one RaggedBatch ``[*batch, max n_i, *d]``.
@@ -162,17 +203,16 @@ def combine_data(data_list: Sequence[Union[Sequence, torch.Tensor]], other_with_
     share = other_with_same_sample_sizes
 
     if flatten_batch_dims:
-        if _bh is not None and (device is None or torch.device(device).type == "cpu"):
-            fast = _bh.pack_cpu(data_list)      # C++ loop; declines (None) for anything but plain CPU tensors
-            if fast is not None:
-                padded, sizes_cpu = fast
-                if share is None:
-                    return RaggedBatch(padded, sample_sizes=sizes_cpu)
-                assert padded.shape[0] == share.sample_sizes.shape[0], \
-                    "Number of samples does not match `other_with_same_sample_sizes`"
-                assert tuple(padded.shape[:2]) == tuple(share.mask.shape), \
-                    "Needed mask dimension does not match `other_with_same_sample_sizes`"
-                return share.create_with_sample_sizes_like_self(padded, non_uniform_dim=1, device=padded.device)
+        fast = _fast_pack(data_list, device) if _bh is not None else None
+        if fast is not None:
+            padded, sizes = fast
+            if share is None:
+                return RaggedBatch(padded, sample_sizes=sizes)
+            assert padded.shape[0] == share.sample_sizes.shape[0], \
+                "Number of samples does not match `other_with_same_sample_sizes`"
+            assert tuple(padded.shape[:2]) == tuple(share.mask.shape), \
+                "Needed mask dimension does not match `other_with_same_sample_sizes`"
+            return share.create_with_sample_sizes_like_self(padded, non_uniform_dim=1, device=padded.device)
         leaves: List[torch.Tensor] = []
         _walk_flat(data_list, leaves)
         if not leaves:

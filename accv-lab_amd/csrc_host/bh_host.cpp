@@ -36,7 +36,7 @@ bool flatten(PyObject* obj, std::vector<at::Tensor>& out)
 }
 
 // combine_data, flatten mode, CPU target: (padded [B, width, *inner], sizes int64 [B]) or None
-py::object pack_cpu(const py::object& data)
+py::object pack_cpu(const py::object& data, bool pin, int64_t max_bytes)
 {
     std::vector<at::Tensor> leaves;
     if (!flatten(data.ptr(), leaves) || leaves.empty()) return py::none();
@@ -57,8 +57,14 @@ py::object pack_cpu(const py::object& data)
     const int64_t b = (int64_t)leaves.size();
     std::vector<int64_t> shape{b, width};
     shape.insert(shape.end(), inner.begin(), inner.end());
-    at::Tensor padded = at::zeros(shape, proto->options());
-    at::Tensor sizes = at::empty({b}, at::TensorOptions().dtype(at::kLong));
+    {
+        int64_t bytes = (int64_t)proto->element_size();
+        for (auto d : shape) bytes *= d;
+        if (max_bytes > 0 && bytes > max_bytes) return py::none();  // caller prefers another route for big batches
+    }
+    // `pin`: the padded batch goes to a GPU next — build it in pinned memory so that ONE asynchronous copy moves it
+    at::Tensor padded = at::zeros(shape, proto->options().pinned_memory(pin));
+    at::Tensor sizes = at::empty({b}, at::TensorOptions().dtype(at::kLong).pinned_memory(pin));
     int64_t* sz = sizes.data_ptr<int64_t>();
     int64_t row_elems = 1;
     for (auto s : inner) row_elems *= s;
@@ -77,6 +83,46 @@ py::object pack_cpu(const py::object& data)
         }
     }
     return py::make_tuple(padded, sizes);
+}
+
+// combine_data, flatten mode, all samples on ONE device (typically the GPU): the python loop that trims / checks the
+// samples and the concatenation, in one call.  Returns (flat [total, *inner], sizes int64 [B] on the CPU,
+// meta int64 [2, B] = (row offsets, sizes) on the CPU — pinned if `pin` —, width) or None.
+py::object cat_leaves(const py::object& data, bool pin)
+{
+    std::vector<at::Tensor> leaves;
+    if (!flatten(data.ptr(), leaves) || leaves.empty()) return py::none();
+    const at::Tensor* proto = nullptr;
+    int64_t width = 0;
+    for (const auto& t : leaves) {
+        if (!t.defined() || t.requires_grad() || t.dim() < 1 || t.is_sparse() || t.is_quantized()) return py::none();
+        width = std::max<int64_t>(width, t.size(0));
+        if (!proto && t.numel() > 0) proto = &t;
+    }
+    if (!proto) return py::none();
+    const auto inner = proto->sizes().slice(1);
+    const int64_t b = (int64_t)leaves.size();
+    at::Tensor meta = at::empty({2, b}, at::TensorOptions().dtype(at::kLong).pinned_memory(pin));
+    int64_t* off = meta.data_ptr<int64_t>();
+    int64_t* sz = off + b;
+    std::vector<at::Tensor> parts;
+    parts.reserve(leaves.size());
+    int64_t total = 0;
+    for (int64_t i = 0; i < b; ++i) {
+        const at::Tensor& t = leaves[(size_t)i];
+        const int64_t n = t.numel() == 0 ? 0 : t.size(0);
+        off[i] = total;
+        sz[i] = n;
+        total += n;
+        if (n == 0) continue;
+        if (t.device() != proto->device() || t.scalar_type() != proto->scalar_type() || t.sizes().slice(1) != inner)
+            return py::none();
+        parts.push_back(t);
+    }
+    at::Tensor flat = parts.size() == 1 ? parts[0].contiguous() : at::cat(parts, 0);
+    at::Tensor sizes = at::empty({b}, at::TensorOptions().dtype(at::kLong));
+    std::memcpy(sizes.data_ptr<int64_t>(), sz, (size_t)b * sizeof(int64_t));
+    return py::make_tuple(flat, sizes, meta, width);
 }
 
 // RaggedBatch.split for one (flattened) batch dimension: views flat[i].narrow(0, 0, sizes[i]) (+ transpose(0, back))
@@ -121,6 +167,7 @@ std::vector<at::Tensor> split_views(const at::Tensor& flat, const std::vector<in
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "host fast path of accvlab.batching_helpers (per-sample pack / split loops)";
-    m.def("pack_cpu", &pack_cpu);
+    m.def("pack_cpu", &pack_cpu, py::arg("data"), py::arg("pin") = false, py::arg("max_bytes") = 0);
+    m.def("cat_leaves", &cat_leaves, py::arg("data"), py::arg("pin") = false);
     m.def("split_views", &split_views);
 }

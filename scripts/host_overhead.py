@@ -57,6 +57,15 @@ def main():
     res["raw ctypes accv_draw_heatmap_batched_f32"] = rate(lambda: lib.accv_draw_heatmap_batched_f32(
         hm.data_ptr(), 4, 0, 64, 64, c.tensor.data_ptr(), r.tensor.data_ptr(), c.sample_sizes.data_ptr(), None, 8, 6.0,
         1.0, 2, stream))
+    import bench_workloads as wl
+    from accvlab.batching_helpers import combine_data
+
+    boxes_cpu = wl.ragged_boxes(64, 1, 32, seed=0)
+    boxes_gpu = [t.to(dev) for t in boxes_cpu]
+    res["combine_data(64 CPU samples -> cuda)"] = rate(lambda: combine_data(boxes_cpu, device=dev), n=500)
+    res["combine_data(64 CUDA samples)"] = rate(lambda: combine_data(boxes_gpu), n=500)
+    rb = combine_data(boxes_gpu)
+    res["RaggedBatch.split (64 CUDA samples, incl. size read-back)"] = rate(lambda: rb.split(), n=500)
     print(json.dumps({k: round(v, 2) for k, v in res.items()}, indent=1))
 
 

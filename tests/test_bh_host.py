@@ -114,3 +114,38 @@ def test_split_of_a_tensor_that_requires_grad_stays_differentiable():
     want[0] = 1.0
     want[1, :2] = 2.0
     assert torch.equal(t.grad, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["cpu", "cuda"])
+@pytest.mark.parametrize("inner,dtype", [((4,), torch.float32), ((), torch.int64), ((2, 3), torch.float16)])
+def test_gpu_target_fast_paths_match_python(source, inner, dtype):
+    dev = torch.device("cuda", 0)
+    data = _samples(7, n=33, inner=inner, dtype=dtype)
+    if source == "cuda":
+        data = [t.to(dev) for t in data]
+    nested = [data[:10], (data[10:20], [data[20]]), data[21:]]
+    for arg in (data, nested):
+        fast, slow = _both(lambda: combine_data(arg, device=dev))
+        assert fast.tensor.device == dev and fast.sample_sizes.device == dev
+        _same_rb(fast, slow)
+    if source == "cuda":
+        fast, slow = _both(lambda: combine_data(data))          # device inferred from the samples
+        _same_rb(fast, slow)
+    # a batch above the direct-transfer limit takes the flat + pack-kernel route
+    big = [torch.randn(int(n), 512).to(dtype if dtype.is_floating_point else torch.float32)
+           for n in torch.randint(1, 40, (64,))]
+    if source == "cuda":
+        big = [t.to(dev) for t in big]
+    fast, slow = _both(lambda: combine_data(big, device=dev))
+    _same_rb(fast, slow)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_gpu_split_views_alias_the_batch():
+    dev = torch.device("cuda", 0)
+    rb = RaggedBatch(torch.randn(5, 6, 3, device=dev), sample_sizes=torch.tensor([6, 0, 2, 5, 1], device=dev))
+    fast, slow = _both(lambda: rb.split())
+    for a, b in zip(fast, slow):
+        assert a.shape == b.shape and a.data_ptr() == b.data_ptr() and torch.equal(a, b)
