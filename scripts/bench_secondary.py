@@ -126,6 +126,24 @@ def c2(num_tensors):
                       "effective_GBps": nbytes / t_mtc / 1e9}))
 
 
+def c2_reverse(num_tensors):
+    """the same tree, but resident on the GPU and copied back to the host (the reference copies every
+    tensor on its own, multi_tensor_copier.cpp:790-800; here: one gather kernel + one transfer per chunk)."""
+    from accvlab.multi_tensor_copier import start_copy
+
+    dev = torch.device("cuda", 0)
+    tree = start_copy(wl.meta_tensor_tree(num_tensors, seed=0), dev).get()
+    leaves = _leaves(tree)
+    nbytes = sum(t.numel() * t.element_size() for t in leaves)
+    sync = torch.cuda.synchronize
+    t_naive = _timeit(lambda: [t.cpu() for t in leaves], 2, 5, sync)
+    t_mtc = _timeit(lambda: start_copy(tree, "cpu").get(), 5, 30, sync)
+    t_nopack = _timeit(lambda: start_copy(tree, "cpu", pack_cpu_tensors=False).get(), 2, 5, sync)
+    print(json.dumps({"config": "C2-reverse (GPU->host)", "tensors": len(leaves), "bytes": nbytes,
+                      "per_tensor_cpu_ms": t_naive * 1e3, "multi_tensor_copier_ms": t_mtc * 1e3,
+                      "multi_tensor_copier_unpacked_ms": t_nopack * 1e3, "speedup_vs_per_tensor": t_naive / t_mtc}))
+
+
 def c3():
     from accvlab.batching_helpers import combine_data
     from accvlab.draw_heatmap import draw_heatmap_batched
@@ -333,6 +351,7 @@ if __name__ == "__main__":
         if "C2" in which:
             c2(a.tensors)
             c2(528)
+            c2_reverse(a.tensors)
         if "C3" in which:
             c3()
         if "H2" in which:
