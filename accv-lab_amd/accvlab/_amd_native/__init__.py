@@ -109,7 +109,10 @@ def stream_ptr(device) -> int:
     import torch
 
     idx = device.index
-    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the accessor torch's own generated code uses
+    if raw is None:  # pragma: no cover - other torch builds
+        return torch.cuda.current_stream(device).cuda_stream
+    return raw(torch.cuda.current_device() if idx is None else idx)
 
 
 class _NoGuard:

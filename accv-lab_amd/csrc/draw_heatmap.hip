@@ -534,6 +534,56 @@ __global__ void bin_fill_kernel(const int32_t* __restrict__ idx, int n, int plan
     }
 }
 
+// count + scan + fill of the three kernels above in ONE single-workgroup launch, for the common small case (a few
+// thousand objects, at most kBinSmallPlanes planes): per-plane counters / cursors live in LDS
+constexpr int kBinSmallPlanes = 8192, kBinSmallObjects = 1 << 16;
+__global__ __launch_bounds__(1024) void bin_small_kernel(const int32_t* __restrict__ idx, int n, int planes,
+                                                         const int2* __restrict__ centers,
+                                                         const int32_t* __restrict__ radii, int* __restrict__ off,
+                                                         int2* __restrict__ sorted_centers,
+                                                         int32_t* __restrict__ sorted_radii)
+{
+    __shared__ int s_cnt[kBinSmallPlanes];
+    __shared__ int s_part[1024];
+    const int t = threadIdx.x;
+    for (int i = t; i < planes; i += 1024) s_cnt[i] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        const int pl = idx[i];
+        if (pl >= 0 && pl < planes) atomicAdd(&s_cnt[pl], 1);
+    }
+    __syncthreads();
+    const int per = (planes + 1023) / 1024;
+    const int lo = min(t * per, planes), hi = min(lo + per, planes);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += s_cnt[i];
+    s_part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (t >= d) ? s_part[t - d] : 0;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    int run = s_part[t] - sum;  // exclusive prefix of this thread's chunk
+    for (int i = lo; i < hi; ++i) {
+        const int c = s_cnt[i];
+        off[i] = run;
+        s_cnt[i] = run;  // becomes the plane's write cursor
+        run += c;
+    }
+    if (t == 1023) off[planes] = s_part[1023];
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        const int pl = idx[i];
+        if (pl >= 0 && pl < planes) {
+            const int dst = atomicAdd(&s_cnt[pl], 1);
+            sorted_centers[dst] = centers[i];
+            sorted_radii[dst] = radii[i];
+        }
+    }
+}
+
 __global__ void fill_kernel(float4* __restrict__ dst, size_t n4, float value)
 {
     const float4 v = make_float4(value, value, value, value);
@@ -656,14 +706,20 @@ int accv_draw_heatmap_flat_f32(float* heatmaps, int num_planes, int height, int 
     int2* sorted_centers = reinterpret_cast<int2*>(sc_raw);
     int32_t* sorted_radii = reinterpret_cast<int32_t*>(sc_raw + accv::align_up((size_t)num_objects * 8, 16));
 
-    if (hipMemsetAsync(cnt, 0, (size_t)num_planes * 4, stream) != hipSuccess)
-        return accv::fail(ACCV_ELAUNCH, "draw_heatmap: memset of the bin counters failed");
-    const int nb = num_objects > 0 ? min((num_objects + 255) / 256, 1024) : 1;
-    if (num_objects > 0) hipLaunchKernelGGL(bin_count_kernel, dim3(nb), dim3(256), 0, stream, heatmap_idxes, num_objects, num_planes, cnt);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, off, num_planes);
-    if (num_objects > 0)
-        hipLaunchKernelGGL(bin_fill_kernel, dim3(nb), dim3(256), 0, stream, heatmap_idxes, num_objects, num_planes, off, cnt,
-                           reinterpret_cast<const int2*>(centers), radii, sorted_centers, sorted_radii);
+    if (num_planes <= kBinSmallPlanes && num_objects <= kBinSmallObjects) {
+        hipLaunchKernelGGL(bin_small_kernel, dim3(1), dim3(1024), 0, stream, heatmap_idxes, num_objects, num_planes,
+                           reinterpret_cast<const int2*>(centers), radii, off, sorted_centers, sorted_radii);
+    } else {
+        if (hipMemsetAsync(cnt, 0, (size_t)num_planes * 4, stream) != hipSuccess)
+            return accv::fail(ACCV_ELAUNCH, "draw_heatmap: memset of the bin counters failed");
+        const int nb = num_objects > 0 ? min((num_objects + 255) / 256, 1024) : 1;
+        if (num_objects > 0)
+            hipLaunchKernelGGL(bin_count_kernel, dim3(nb), dim3(256), 0, stream, heatmap_idxes, num_objects, num_planes, cnt);
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, off, num_planes);
+        if (num_objects > 0)
+            hipLaunchKernelGGL(bin_fill_kernel, dim3(nb), dim3(256), 0, stream, heatmap_idxes, num_objects, num_planes, off,
+                               cnt, reinterpret_cast<const int2*>(centers), radii, sorted_centers, sorted_radii);
+    }
     if (int rc = accv::check_launch("draw_heatmap binning")) return rc;
 
     SplatParams p{};

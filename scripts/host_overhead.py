@@ -57,6 +57,27 @@ def main():
     res["raw ctypes accv_draw_heatmap_batched_f32"] = rate(lambda: lib.accv_draw_heatmap_batched_f32(
         hm.data_ptr(), 4, 0, 64, 64, c.tensor.data_ptr(), r.tensor.data_ptr(), c.sample_sizes.data_ptr(), None, 8, 6.0,
         1.0, 2, stream))
+    from accvlab.draw_heatmap import draw_heatmap
+
+    fc = c.tensor.reshape(-1, 2).contiguous()
+    fr = r.tensor.reshape(-1).contiguous()
+    fi = torch.arange(4, device=dev, dtype=torch.int32).repeat_interleave(8)
+    res["draw_heatmap flat API (64x64, 32 objects; host side)"] = rate(lambda: draw_heatmap(hm, fc, fr, fi, 6.0, 1.0))
+
+    def gpu_time(fn, n=300):
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+
+    res["draw_heatmap flat API (64x64) us per call incl. GPU"] = gpu_time(lambda: draw_heatmap(hm, fc, fr, fi, 6.0, 1.0))
+    res["draw_heatmap_batched (64x64) us per call incl. GPU"] = gpu_time(lambda: draw_heatmap_batched(hm, c, r, 6.0, 1.0))
     import bench_workloads as wl
     from accvlab.batching_helpers import combine_data
 

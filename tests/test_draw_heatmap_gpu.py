@@ -197,6 +197,21 @@ def test_flat_many_objects_unsorted_and_out_of_range_planes():
     _close(hm, ref, "flat many")
 
 
+@pytest.mark.parametrize("P,H,W,N", [(9000, 8, 16, 20000),     # more planes than the single-launch binning handles
+                                     (5, 32, 64, 70000)])      # more objects than it handles
+def test_flat_large_counts_take_the_multi_kernel_binning(P, H, W, N):
+    draw_heatmap, _ = _dh()
+    g = np.random.RandomState(4)
+    c = np.stack([g.randint(-3, W + 3, N), g.randint(-3, H + 3, N)], 1).astype(np.int32)
+    r = g.randint(0, 4, N).astype(np.int32)
+    idx = g.randint(-1, P + 1, N).astype(np.int32)
+    ref = np.zeros((P, H, W), dtype=np.float32)
+    oracle.draw_heatmap_flat(ref, c, r, idx, 6.0, 1.0)
+    hm = torch.zeros((P, H, W), device=DEV)
+    draw_heatmap(hm, _t(c), _t(r), _t(idx))
+    _close(hm, ref, "flat large counts")
+
+
 def test_idempotent_and_monotone():
     """size-independent properties at BASELINE's full size: drawing twice changes nothing; in-place draw on
     a zero map equals the fused clear; result >= base everywhere."""
