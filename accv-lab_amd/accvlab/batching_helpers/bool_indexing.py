@@ -9,7 +9,7 @@ take the torch path (the reference runs there too).
 """
 from __future__ import annotations
 
-from typing import Any, List, NamedTuple, Sequence, Union
+from typing import Any, List, NamedTuple, Optional, Sequence, Union
 
 import torch
 
@@ -66,8 +66,10 @@ def _limit_columns(m: torch.Tensor, valid) -> torch.Tensor:
     return m & (torch.arange(m.shape[1], device=m.device).unsqueeze(0) < valid.to(m.device).unsqueeze(1))
 
 
-def _compact_indices(m: torch.Tensor, valid):
-    """(indices [B, M] int64 zero-filled, counts [B] int64, max count) — one sync for the max."""
+def _compact_indices(m: torch.Tensor, valid, bound: Optional[int] = None):
+    """(indices [B, M] int64 zero-filled, counts [B] int64, result width).  The width is the largest count, which
+    costs the one host synchronisation of these operators (it decides an output SHAPE) — unless the caller supplies
+    an upper ``bound``: then the width is the bound, counts are clamped to it, and nothing synchronises."""
     if m.is_cuda:
         idx, sizes = _ext.mask_to_indices(m, valid)
     else:
@@ -76,6 +78,9 @@ def _compact_indices(m: torch.Tensor, valid):
         order = torch.argsort((~mm).to(torch.int8), dim=1, stable=True)
         keep = torch.arange(m.shape[1]).unsqueeze(0) < sizes.unsqueeze(1)
         idx = torch.where(keep, order, torch.zeros_like(order))
+    if bound is not None:
+        longest = max(0, min(int(bound), m.shape[1]))
+        return idx, sizes.clamp(max=longest), longest
     longest = int(sizes.max().item()) if sizes.numel() > 0 else 0
     return idx, sizes, longest
 
@@ -100,12 +105,18 @@ def _gather(data_t: torch.Tensor, idx: torch.Tensor, sizes: torch.Tensor, longes
 
 
 def batched_bool_indexing(input_data: Union[RaggedBatch, torch.Tensor],
-                          input_mask: Union[RaggedBatch, torch.Tensor]) -> RaggedBatch:
+                          input_mask: Union[RaggedBatch, torch.Tensor], *,
+                          max_sample_size: Optional[int] = None) -> RaggedBatch:
     """Per-sample boolean indexing along the non-uniform dimension (``dim == 1`` for plain tensors): sample ``i`` of
     the result holds, in order, the entries of ``input_data[i]`` whose mask entry is True.  The result is a
     RaggedBatch with the per-sample True counts as sample sizes and zeros in the padding.  When exactly one
     argument is a RaggedBatch its sample sizes also bound the other argument; with two tensors every column is
-    valid.  Several batch dimensions are supported when both arguments are RaggedBatch instances."""
+    valid.  Several batch dimensions are supported when both arguments are RaggedBatch instances.
+
+    ``max_sample_size`` (extension): an upper bound of the per-sample True counts known to the caller.  The result
+    then has exactly that width and the call does not synchronise with the host (usable inside a captured graph);
+    without it the width is the largest count, read back from the device as in the reference
+    (batched_bool_indexing.py:198).  Entries beyond the bound are dropped."""
     _check_pair(input_data, input_mask)
     d_rb = isinstance(input_data, RaggedBatch)
     batch_shape = input_data.batch_shape if d_rb else torch.Size([input_data.shape[0]])
@@ -118,7 +129,7 @@ def batched_bool_indexing(input_data: Union[RaggedBatch, torch.Tensor],
         data_t = input_data.get_non_uniform_dimension_transposed_to(1).tensor
     else:
         data_t = input_data
-    idx, sizes, longest = _compact_indices(m, valid)
+    idx, sizes, longest = _compact_indices(m, valid, max_sample_size)
     out = RaggedBatch(_gather(data_t, idx, sizes, longest), sample_sizes=sizes, non_uniform_dim=1)
     if d_rb:
         if multi:
@@ -172,12 +183,13 @@ def batched_bool_indexing_write(to_write: RaggedBatch, output_mask: Union[Ragged
     return res
 
 
-def get_compact_lists(mask: torch.Tensor, data: Sequence[Union[torch.Tensor, Any]]) -> List[Union[RaggedBatch, Any]]:
+def get_compact_lists(mask: torch.Tensor, data: Sequence[Union[torch.Tensor, Any]], *,
+                      max_sample_size: Optional[int] = None) -> List[Union[RaggedBatch, Any]]:
     """Left-compact every tensor of ``data`` (each ``[B, M, ...]``) along ``dim == 1`` by the 2-D ``mask`` into a
     RaggedBatch of width ``max(mask.sum(1))``; non-tensor items pass through unchanged.  The compaction indices
-    are computed once and shared by all tensors."""
+    are computed once and shared by all tensors.  ``max_sample_size`` (extension): see :func:`batched_bool_indexing`."""
     m = mask.bool() if mask.dtype != torch.bool else mask
-    idx, sizes, longest = _compact_indices(m, None)
+    idx, sizes, longest = _compact_indices(m, None, max_sample_size)
     out: List[Any] = []
     for el in data:
         if isinstance(el, torch.Tensor):
@@ -192,12 +204,14 @@ def get_compact_lists(mask: torch.Tensor, data: Sequence[Union[torch.Tensor, Any
     return out
 
 
-def get_compact_from_named_tuple(mask: torch.Tensor, data: NamedTuple) -> NamedTuple:
+def get_compact_from_named_tuple(mask: torch.Tensor, data: NamedTuple, *,
+                                 max_sample_size: Optional[int] = None) -> NamedTuple:
     """:func:`get_compact_lists` for a named tuple; the result has the same named-tuple type."""
-    return type(data)(*get_compact_lists(mask, data))
+    return type(data)(*get_compact_lists(mask, data, max_sample_size=max_sample_size))
 
 
-def get_indices_from_mask(mask: Union[torch.Tensor, RaggedBatch]) -> RaggedBatch:
+def get_indices_from_mask(mask: Union[torch.Tensor, RaggedBatch], *,
+                          max_sample_size: Optional[int] = None) -> RaggedBatch:
     """Per sample, the positions of the True mask entries (int64, in order) as a RaggedBatch.  2-D masks only
     (one batch dimension)."""
     valid = None
@@ -206,5 +220,5 @@ def get_indices_from_mask(mask: Union[torch.Tensor, RaggedBatch]) -> RaggedBatch
         valid = mask.sample_sizes
         mask = mask.tensor
     assert mask.ndim == 2, "Only 2D masks (batch_size, num_elements) are supported"
-    idx, sizes, longest = _compact_indices(mask, valid)
+    idx, sizes, longest = _compact_indices(mask, valid, max_sample_size)
     return RaggedBatch(idx[:, :longest].contiguous(), sample_sizes=sizes)

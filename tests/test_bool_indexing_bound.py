@@ -1,0 +1,75 @@
+"""Sync-free compaction (extension): ``max_sample_size=`` on batched_bool_indexing / get_compact_lists /
+get_indices_from_mask gives the result a caller-known width instead of reading the largest count back from the device
+(the one host synchronisation of these operators decides an output shape,
+batched_bool_indexing.py:198 / batched_processing_py.py:245-246 of the reference)."""
+import pytest
+import torch
+
+from accvlab.batching_helpers import (RaggedBatch, batched_bool_indexing, get_compact_lists, get_indices_from_mask)
+
+
+def _case(dev, seed=0, b=6, m=20, d=3):
+    g = torch.Generator().manual_seed(seed)
+    data = torch.randn(b, m, d, generator=g).to(dev)
+    mask = (torch.rand(b, m, generator=g) < 0.4).to(dev)
+    return data, mask
+
+
+def _check(dev):
+    data, mask = _case(dev)
+    ref = batched_bool_indexing(data, mask)                      # reference behaviour (one read-back)
+    longest = ref.tensor.shape[1]
+    for bound in (longest, longest + 5, 20, 100):
+        got = batched_bool_indexing(data, mask, max_sample_size=bound)
+        w = min(bound, 20)
+        assert got.tensor.shape == (6, w, 3)
+        assert torch.equal(got.sample_sizes, ref.sample_sizes)
+        assert torch.equal(got.tensor[:, :longest], ref.tensor) and (got.tensor[:, longest:] == 0).all()
+    # a bound below the true maximum drops the tail of the longer samples
+    small = max(longest - 2, 0)
+    got = batched_bool_indexing(data, mask, max_sample_size=small)
+    assert got.tensor.shape[1] == small
+    assert torch.equal(got.sample_sizes, ref.sample_sizes.clamp(max=small))
+    keep = torch.arange(small, device=dev).unsqueeze(0) < got.sample_sizes.unsqueeze(1)
+    assert torch.equal(got.tensor[keep], ref.tensor[:, :small][keep])
+    # the other entry points share the switch
+    idx_ref = get_indices_from_mask(mask)
+    idx = get_indices_from_mask(mask, max_sample_size=longest + 3)
+    assert idx.tensor.shape[1] == longest + 3 and torch.equal(idx.tensor[:, :longest], idx_ref.tensor)
+    a, b_, other = get_compact_lists(mask, [data, data[..., 0], "x"], max_sample_size=longest + 1)
+    assert a.tensor.shape[1] == longest + 1 and b_.tensor.shape[1] == longest + 1 and other == "x"
+    assert torch.equal(a.tensor[:, :longest], ref.tensor)
+    # ragged mask input
+    rmask = RaggedBatch(mask, sample_sizes=torch.tensor([20, 3, 0, 10, 20, 7], device=dev))
+    r_ref = batched_bool_indexing(data, rmask)
+    r_got = batched_bool_indexing(data, rmask, max_sample_size=20)
+    assert torch.equal(r_got.sample_sizes, r_ref.sample_sizes)
+    assert torch.equal(r_got.tensor[:, :r_ref.tensor.shape[1]], r_ref.tensor)
+
+
+def test_bound_cpu():
+    _check(torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_bound_gpu_and_graph_capture():
+    dev = torch.device("cuda", 0)
+    _check(dev)
+    # with a bound nothing synchronises: the whole compaction can be captured into one hipGraph and replayed
+    data, mask = _case(dev, seed=1)
+    static_data, static_mask = data.clone(), mask.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        batched_bool_indexing(static_data, static_mask, max_sample_size=12)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = batched_bool_indexing(static_data, static_mask, max_sample_size=12)
+    for seed in (2, 3):
+        d2, m2 = _case(dev, seed=seed)
+        static_data.copy_(d2)
+        static_mask.copy_(m2)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = batched_bool_indexing(d2, m2, max_sample_size=12)
+        assert torch.equal(out.tensor, want.tensor) and torch.equal(out.sample_sizes, want.sample_sizes)
