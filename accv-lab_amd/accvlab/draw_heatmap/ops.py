@@ -232,3 +232,69 @@ def get_centers_and_radii(centers, bboxes, out_size_factor: float):
         nu = centers.non_uniform_dim
         return centers.create_with_sample_sizes_like_self(out_c, nu), centers.create_with_sample_sizes_like_self(out_r, nu)
     return out_c, out_r
+
+
+def draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diameter_to_sigma_factor: float = 6.0,
+                            k_scale: float = 1.0, *, clear: bool = False) -> None:
+    """(extension) Rasterise one batch of objects at several strides.  Equivalent to, for every scale ``s``::
+
+        c, r = get_centers_and_radii(centers, bboxes, out_size_factors[s])
+        draw_heatmap_batched(heatmaps[s], c, r, diameter_to_sigma_factor, k_scale, clear=clear)
+
+    but up to four scales run as ONE kernel launch that converts the float centres / boxes inside its culling step
+    (no intermediate tensors): small target maps are launch bound, not bandwidth bound.
+
+    Args:
+        heatmaps: sequence of float32 ``[B, H_s, W_s]`` tensors (modified in place).
+        centers: RaggedBatch float32 ``[B, Nmax, 2]`` (x, y) in source-image pixels.
+        bboxes: RaggedBatch (or tensor) float32 ``[B, Nmax, 4]`` (x0, y0, x1, y1) in source-image pixels.
+        out_size_factors: one stride per heat-map.
+    """
+    heatmaps = list(heatmaps)
+    strides = [float(f) for f in out_size_factors]
+    if not (len(heatmaps) == len(strides) and len(heatmaps) >= 1):
+        raise RuntimeError("heatmaps and out_size_factors must have the same, non-zero length")
+    c_t = centers.tensor
+    b_t = bboxes.tensor if hasattr(bboxes, "tensor") else bboxes
+    counts = centers.sample_sizes
+    if counts.dtype not in (torch.int32, torch.int64):
+        counts = counts.to(torch.int64)
+    _check_input(c_t, "centers")
+    _check_input(b_t, "bboxes")
+    _check_input(counts, "nums_targets")
+    if not (c_t.dim() == 3 and c_t.size(2) == 2):
+        raise RuntimeError("centers must be of shape [batch_size, num_targets, 2]")
+    if not (b_t.dim() == 3 and b_t.size(2) == 4 and b_t.shape[:2] == c_t.shape[:2]):
+        raise RuntimeError("bboxes must be of shape [batch_size, num_targets, 4]")
+    _check_dtype(c_t, torch.float32, "centers")
+    _check_dtype(b_t, torch.float32, "bboxes")
+    batch, n_max = c_t.shape[:2]
+    if not (counts.dim() == 1 and counts.size(0) == batch):
+        raise RuntimeError("nums_targets must be of shape [batch_size]")
+    fusable = len(heatmaps) <= 4
+    for hm in heatmaps:
+        _check_input(hm, "heatmap")
+        _check_dtype(hm, torch.float32, "heatmap")
+        if not (hm.dim() == 3 and hm.size(0) == batch):
+            raise RuntimeError("every heatmap must be of shape [batch_size, height, width]")
+        _same_device(hm, ("centers", c_t), ("bboxes", b_t), ("nums_targets", counts))
+        fusable = fusable and hm.size(2) % 4 == 0 and hm.data_ptr() % 16 == 0 and hm.size(1) * hm.size(2) * 4 < (1 << 31)
+    if not fusable:   # odd widths / more than four scales: the per-scale operators
+        for hm, f in zip(heatmaps, strides):
+            ci, ri = get_centers_and_radii(centers, bboxes, f)
+            draw_heatmap_batched(hm, ci, ri, diameter_to_sigma_factor, k_scale, clear=clear)
+        return
+    import ctypes
+
+    n = len(heatmaps)
+    ptrs = (ctypes.c_void_p * n)(*[hm.data_ptr() for hm in heatmaps])
+    hs = (ctypes.c_int * n)(*[hm.size(1) for hm in heatmaps])
+    ws = (ctypes.c_int * n)(*[hm.size(2) for hm in heatmaps])
+    st = (ctypes.c_float * n)(*strides)
+    flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0)
+    dev = heatmaps[0].device
+    with _nat.device_guard(dev):
+        status = _nat.lib().accv_draw_heatmap_multiscale_f32(
+            ptrs, hs, ws, st, n, batch, c_t.data_ptr(), b_t.data_ptr(), counts.data_ptr(), n_max,
+            float(diameter_to_sigma_factor), float(k_scale), flags, _nat.stream_ptr(dev))
+    _nat.check(status, "draw_heatmap_multiscale")

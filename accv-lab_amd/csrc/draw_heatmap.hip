@@ -44,6 +44,17 @@ struct SplatParams {
     float factor, k;
     int counts_i64;
     int grid3d;           // tile index comes from a 3-D grid instead of a linear block index
+    // multi-scale front end (SRC == 1): objects are float centres / boxes in source pixels, converted per scale
+    const float* centers_f;  // [B, n_max, 2] (x, y)
+    const float* boxes_f;    // [B, n_max, 4] (x0, y0, x1, y1)
+    float stride;
+};
+
+constexpr int kMaxScales = 4;
+struct MultiParams {
+    SplatParams scale[kMaxScales];
+    long long tile_begin[kMaxScales + 1];  // linear workgroup index where each scale's tiles start
+    int n_scales;
 };
 
 // one culled hit, read back as a single ds_read_b128 broadcast.  The clipped box is stored relative to the tile and
@@ -87,12 +98,15 @@ struct TileCtx {
     const int2* centers2;    // objects of this plane: [0, n)
     const int32_t* radii;
     const int32_t* labels;
+    const float2* centers_f;  // SRC == 1: float objects of this plane
+    const float4* boxes_f;
+    float stride;
     int n, cls;              // cls < 0: no class filter
 };
 
 // tile coordinates from the launch geometry + the object range that feeds this plane; false = wave has no tile
 template <int TW, int TH, int WPG>
-__device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, TileCtx& t)
+__device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, TileCtx& t, long long linear_group)
 {
     int tx, ty;
     if (p.grid3d) {
@@ -102,7 +116,7 @@ __device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, Tile
         t.plane = blockIdx.z;
         if (tx >= p.tiles_x) return false;
     } else {  // linear block index (more than 65535 planes or tile rows)
-        const long long tile = (long long)blockIdx.x * WPG + wave;
+        const long long tile = linear_group * WPG + wave;
         if (tile >= p.n_tiles) return false;  // whole wave exits; waves never synchronise with each other
         tx = (int)(tile % p.tiles_x);
         const long long t2 = tile / p.tiles_x;
@@ -134,6 +148,9 @@ __device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, Tile
     t.centers2 = reinterpret_cast<const int2*>(p.centers) + obj_base;
     t.radii = p.radii + obj_base;
     t.labels = p.labels + obj_base;
+    t.centers_f = reinterpret_cast<const float2*>(p.centers_f) + obj_base;
+    t.boxes_f = reinterpret_cast<const float4*>(p.boxes_f) + obj_base;
+    t.stride = p.stride;
     return true;
 }
 
@@ -144,11 +161,24 @@ __device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, Tile
 struct Cand {
     int x, y, r, label;
 };
+template <int SRC = 0>
 __device__ __forceinline__ Cand cull_load(const TileCtx& t, int base, int lane)
 {
     const int cc = min(base + lane, t.n - 1);  // n >= 1 inside the candidate loop
-    const int2 cxy = t.centers2[cc];
-    return Cand{cxy.x, cxy.y, t.radii[cc], t.labels[cc]};
+    if constexpr (SRC == 1) {
+        // float centre + box in source pixels -> integer target at this scale, exactly targets_from_boxes_kernel below
+        // (packages/draw_heatmap/tests/_test_helpers.py:20-28): r = max(1, ceil(min edge distance / stride)),
+        // c = int(c / stride); IEEE division
+        const float2 c = t.centers_f[cc];
+        const float4 b = t.boxes_f[cc];
+        const float m = fminf(fminf(c.x - b.x, c.y - b.y), fminf(b.z - c.x, b.w - c.y));
+        int r = (int)ceilf(__fdiv_rn(m, t.stride));
+        if (r < 1) r = 1;
+        return Cand{(int)__fdiv_rn(c.x, t.stride), (int)__fdiv_rn(c.y, t.stride), r, 0};
+    } else {
+        const int2 cxy = t.centers2[cc];
+        return Cand{cxy.x, cxy.y, t.radii[cc], t.labels[cc]};
+    }
 }
 __device__ __forceinline__ unsigned long long cull_test(const TileCtx& t, int base, int lane, const Cand& c)
 {
@@ -159,9 +189,10 @@ __device__ __forceinline__ unsigned long long cull_test(const TileCtx& t, int ba
                      xc + rc >= t.tx0 && yc - rc < t.ty1 && yc + rc >= t.ty0;
     return __ballot(hit);
 }
+template <int SRC = 0>
 __device__ __forceinline__ unsigned long long cull_round(const TileCtx& t, int base, int lane, int& x, int& y, int& r)
 {
-    const Cand c = cull_load(t, base, lane);
+    const Cand c = cull_load<SRC>(t, base, lane);
     x = c.x;
     y = c.y;
     r = c.r;
@@ -183,10 +214,10 @@ __device__ __forceinline__ Hit make_hit(const SplatParams& p, const TileCtx& t, 
     return Hit{x, y, c2, box};
 }
 
-template <int PX, int R, bool CLEAR, int SM, int WPG = kWavesPerGroup>
-__global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
+template <int PX, int R, bool CLEAR, int SM, int WPG, int SRC>
+__device__ __forceinline__ void splat_body(const SplatParams& p, long long linear_group)
 {
-    constexpr int kWavesPerGroup = WPG;  // shadows the namespace constant inside the kernel
+    constexpr int kWavesPerGroup = WPG;  // shadows the namespace constant inside the body
     constexpr int TW = 32 * PX;  // 32 lanes side by side cover one row segment of the tile
     constexpr int TH = 2 * R;    // the two half-waves take R rows each
     static_assert(R % 4 == 0, "row registers are fetched four at a time");
@@ -197,7 +228,7 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     TileCtx t;
-    if (!locate_tile<TW, TH, kWavesPerGroup>(p, wave, t)) return;
+    if (!locate_tile<TW, TH, kWavesPerGroup>(p, wave, t, linear_group)) return;
     const int tx0 = t.tx0, ty0 = t.ty0, n = t.n;
     const long long plane = t.plane;
 
@@ -216,7 +247,7 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
     for (int base = 0; base < n; base += kCand) {
         // ---- cull: conservative 32-bit test, ballot, popcount-prefix compaction into LDS
         int x, y, r;
-        const unsigned long long m = cull_round(t, base, lane, x, y, r);
+        const unsigned long long m = cull_round<SRC>(t, base, lane, x, y, r);
         const bool hit = (m >> lane) & 1ull;
         const int nh = __popcll(m);
         if (nh == 0) continue;
@@ -314,6 +345,26 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
     }
 }
 
+template <int PX, int R, bool CLEAR, int SM, int WPG = kWavesPerGroup>
+__global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
+{
+    splat_body<PX, R, CLEAR, SM, WPG, 0>(p, blockIdx.x);
+}
+
+// ---------------------------------------------------------------- multi-scale: all strides of one batch in ONE launch
+// A detection head wants the same objects rasterised at several strides (config 3: 4 / 8 / 16).  Per scale that is a
+// target-prep launch plus a splat launch of a map of a few MB — launch bound.  Here one grid covers the tiles of every
+// scale; a workgroup finds its scale from the tile prefix (wave-uniform), and the candidates are the FLOAT centres and
+// boxes in source pixels, converted to that scale's integer centre / radius inside the cull (same arithmetic as
+// targets_from_boxes_kernel), so the front end needs no launch and no intermediate tensors at all.
+template <bool CLEAR, int SM>
+__global__ __launch_bounds__(64) void splat_multi_kernel(const MultiParams mp)
+{
+    int s = 0;
+    while (s + 1 < mp.n_scales && (long long)blockIdx.x >= mp.tile_begin[s + 1]) ++s;
+    splat_body<4, 8, CLEAR, SM, 1, 1>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s]);
+}
+
 // ---------------------------------------------------------------- small splats (lane rasters, point-like targets)
 // The tile kernel above pays a full 128x16-pixel register update per hit, whatever the size of the object's box.  For
 // boxes of a few pixels (a lane sample of radius 2 covers 5x5) that is 2048 pixel updates for 25 useful ones, and
@@ -330,7 +381,7 @@ __global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
 
     const int lane = threadIdx.x & 63;
     TileCtx t;
-    if (!locate_tile<TW, TH, 1>(p, 0, t)) return;
+    if (!locate_tile<TW, TH, 1>(p, 0, t, blockIdx.x)) return;
     const int sub = lane >> 5, col0 = t.tx0 + (lane & 31) * 4;
 
     // "untouched" is -inf in the LDS tile (fused-clear mode starts from 0 = the cleared map)
@@ -770,6 +821,83 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
     p.counts_i64 = (flags & ACCV_HM_COUNTS_I64) ? 1 : 0;
     const long long planes = (long long)batch * (num_classes > 0 ? num_classes : 1);
     return dispatch_splat(p, planes, clear, (flags & ACCV_HM_SMALL_RADII) != 0, stream);
+}
+
+int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights, const int* widths, const float* strides,
+                                     int num_scales, int batch, const float* centers_xy, const float* boxes_xyxy,
+                                     const void* counts, int max_num_targets, float diameter_to_sigma_factor,
+                                     float k_scale, unsigned flags, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (num_scales < 1 || num_scales > kMaxScales)
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: 1..%d scales supported, got %d", kMaxScales, num_scales);
+    if (!heatmaps || !heights || !widths || !strides) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: null array");
+    if (batch < 0 || max_num_targets < 0) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: negative count");
+    if (max_num_targets > (1 << 30))
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: more than 2^30 objects per sample");
+    if (batch == 0) return ACCV_OK;
+    if (!counts) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: counts pointer is null");
+    if (max_num_targets > 0 && (!centers_xy || !boxes_xyxy))
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: null object array");
+    if ((reinterpret_cast<uintptr_t>(boxes_xyxy) & 15u) || (reinterpret_cast<uintptr_t>(centers_xy) & 7u))
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: centres need 8-byte and boxes 16-byte alignment");
+    const bool clear = (flags & ACCV_HM_CLEAR) != 0;
+    if (max_num_targets == 0 && !clear) return ACCV_OK;
+
+    MultiParams mp{};
+    long long tiles = 0;
+    size_t total_bytes = 0;
+    int used = 0;
+    for (int i = 0; i < num_scales; ++i) {
+        if (int rc = check_common(heatmaps[i], heights[i], widths[i], diameter_to_sigma_factor, "draw_heatmap_multiscale"))
+            return rc;
+        if (!(strides[i] > 0.0f)) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: stride %d is not positive", i);
+        if (heights[i] == 0 || widths[i] == 0) continue;
+        if (!heatmaps[i]) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: heatmap %d is null", i);
+        if (widths[i] % 4 != 0 || (reinterpret_cast<uintptr_t>(heatmaps[i]) & 15u) ||
+            (size_t)heights[i] * widths[i] * sizeof(float) >= ((size_t)1 << 31))
+            return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: map %d needs a width that is a multiple of 4, a 16-byte "
+                                           "aligned base and planes below 2 GiB (use the per-scale calls otherwise)", i);
+        SplatParams& p = mp.scale[used];
+        p.hm = heatmaps[i];
+        p.counts = counts;
+        p.H = heights[i];
+        p.W = widths[i];
+        p.n_max = max_num_targets;
+        p.factor = diameter_to_sigma_factor;
+        p.k = k_scale;
+        p.counts_i64 = (flags & ACCV_HM_COUNTS_I64) ? 1 : 0;
+        p.centers_f = centers_xy;
+        p.boxes_f = boxes_xyxy;
+        p.stride = strides[i];
+        p.tiles_x = (p.W + 127) / 128;
+        p.tiles_y = (p.H + 15) / 16;
+        p.n_tiles = (long long)batch * p.tiles_x * p.tiles_y;
+        p.grid3d = 0;
+        mp.tile_begin[used] = tiles;
+        tiles += p.n_tiles;
+        total_bytes += (size_t)batch * p.H * p.W * sizeof(float);
+        ++used;
+    }
+    mp.n_scales = used;
+    mp.tile_begin[used] = tiles;
+    if (used == 0 || tiles == 0) return ACCV_OK;
+    if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: %lld tiles exceed the grid limit", tiles);
+    int nt = accv::tune_get("hm_nt", -1);
+    if (nt < 0) nt = total_bytes > ((size_t)128 << 20) ? 4 : 0;   // same store policy as the single-scale path
+    const dim3 grid((unsigned)tiles), block(64);
+    if (clear) {
+        if (nt >= 2)
+            hipLaunchKernelGGL((splat_multi_kernel<true, 4>), grid, block, 0, stream, mp);
+        else
+            hipLaunchKernelGGL((splat_multi_kernel<true, 0>), grid, block, 0, stream, mp);
+    } else {
+        if (nt >= 2)
+            hipLaunchKernelGGL((splat_multi_kernel<false, 4>), grid, block, 0, stream, mp);
+        else
+            hipLaunchKernelGGL((splat_multi_kernel<false, 0>), grid, block, 0, stream, mp);
+    }
+    return accv::check_launch("draw_heatmap multi-scale splat kernel");
 }
 
 int accv_heatmap_targets_from_boxes_f32(const float* centers_xy, const float* boxes_xyxy, long long num_objects,

@@ -64,6 +64,18 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
                                   const int32_t* labels, int max_num_targets, float diameter_to_sigma_factor,
                                   float k_scale, unsigned flags, void* stream);
 
+/* Multi-scale target maps in ONE launch (BASELINE config 3; SURVEY §8 f2 fused into H1): for every scale s,
+ *   (c, r) = targets_from_boxes(centers_xy, boxes_xyxy, strides[s])   — packages/draw_heatmap/tests/_test_helpers.py:20-28
+ *   draw_heatmap_batched(heatmaps[s] f32[batch, heights[s], widths[s]], c, r, counts, factor, k)
+ * with the float -> integer conversion done inside the kernel's culling step (no intermediate tensors).  Results are
+ * identical to the per-scale calls.  heatmaps / heights / widths / strides are HOST arrays of `num_scales` (<= 4)
+ * entries; centers f32[batch, Nmax, 2], boxes f32[batch, Nmax, 4] (source pixels), counts as in the batched call.
+ * Every map needs width % 4 == 0, a 16-byte aligned base and planes below 2 GiB (else use the per-scale calls). */
+int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights, const int* widths, const float* strides,
+                                     int num_scales, int batch, const float* centers_xy, const float* boxes_xyxy,
+                                     const void* counts, int max_num_targets, float diameter_to_sigma_factor,
+                                     float k_scale, unsigned flags, void* stream);
+
 /* Target-prep front end: float centres [n,2] (x,y) and boxes [n,4] (x0,y0,x1,y1) in source pixels ->
  * int32 centres [n,2] = int(c / stride) and radii [n] = max(1, int(ceil(min edge distance / stride))) in ONE kernel.
  * Semantics of get_centers_and_radii (packages/draw_heatmap/tests/_test_helpers.py:20-28; the DALI path uses

@@ -183,6 +183,27 @@ def c3():
                       "bytes_per_frame": nbytes // B, "hipgraph_ms_per_batch": tg * 1e3,
                       "hipgraph_frames_per_s": B / tg, "hipgraph_GBps": nbytes / tg / 1e9}))
 
+    # the same three maps from the FLOAT boxes in one launch (front end fused into the cull), vs front end + draw per scale
+    from accvlab.draw_heatmap import draw_heatmap_multiscale, get_centers_and_radii
+
+    crb_f = combine_data(centers_f, device=dev)
+    brb_f = combine_data(boxes_f, device=dev, other_with_same_sample_sizes=crb_f)
+    maps = [hm for hm, _, _ in scales]
+
+    def step_unfused():
+        for hm, s in zip(maps, (4.0, 8.0, 16.0)):
+            ci, ri = get_centers_and_radii(crb_f, brb_f, s)
+            draw_heatmap_batched(hm, ci, ri, 6.0, 1.0, clear=True)
+
+    def step_fused():
+        draw_heatmap_multiscale(maps, crb_f, brb_f, (4.0, 8.0, 16.0), 6.0, 1.0, clear=True)
+
+    tu = _timeit(step_unfused, 50, 500, torch.cuda.synchronize)
+    tf = _timeit(step_fused, 50, 500, torch.cuda.synchronize)
+    print(json.dumps({"config": "C3 from float boxes", "metric": "bbox front end + 3 maps per batch of 32",
+                      "per_scale_ops_ms": tu * 1e3, "draw_heatmap_multiscale_ms": tf * 1e3,
+                      "multiscale_frames_per_s": B / tf, "multiscale_GBps": nbytes / tf / 1e9, "speedup": tu / tf}))
+
     # + lane raster: 8 lanes x 24 points per frame in source pixels, sampled at 256/128/64 arc-length positions (sample
     # spacing ~ the splat radius at every scale) and splatted with radius 2 into one lane map per scale
     # (sampler -> int targets -> fused clear+draw: 3 launches per scale)

@@ -1,0 +1,99 @@
+"""draw_heatmap_multiscale (extension; BASELINE config 3): all strides of a batch in one launch == the per-scale
+composition get_centers_and_radii + draw_heatmap_batched (bit for bit: same arithmetic in the same order per pixel),
+and == the CPU oracle fed with the reference front-end rule (packages/draw_heatmap/tests/_test_helpers.py:20-28)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import h1 as oracle
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _objects(b, n_max, sw, sh, seed):
+    from accvlab.batching_helpers import combine_data
+
+    g = torch.Generator().manual_seed(seed)
+    cs, bs = [], []
+    for _ in range(b):
+        n = int(torch.randint(0, n_max + 1, (1,), generator=g))
+        c = torch.rand(n, 2, generator=g) * torch.tensor([sw, sh])
+        half = torch.rand(n, 4, generator=g) * min(sw, sh) * 0.15
+        cs.append(c)
+        bs.append(torch.cat([c - half[:, :2], c + half[:, 2:]], 1))
+    crb = combine_data(cs, device=DEV)
+    brb = combine_data(bs, device=DEV, other_with_same_sample_sizes=crb)
+    return crb, brb
+
+
+@pytest.mark.parametrize("clear", [True, False])
+@pytest.mark.parametrize("strides,sw,sh", [((4.0, 8.0, 16.0), 960, 544), ((2.0,), 256, 64), ((1.0, 3.0, 4.0, 32.0), 384, 96)])
+def test_multiscale_equals_per_scale_calls_and_oracle(clear, strides, sw, sh):
+    from accvlab.draw_heatmap import draw_heatmap_batched, draw_heatmap_multiscale, get_centers_and_radii
+
+    b = 5
+    crb, brb = _objects(b, 24, sw, sh, seed=int(sum(strides)))
+    shapes = [(b, -(-int(sh / s) // 1), -(-int(sw / s) // 4) * 4) for s in strides]     # widths: multiples of 4
+    base = [torch.rand(sh_, generator=torch.Generator().manual_seed(i)).mul_(0.2).to(DEV) for i, sh_ in enumerate(shapes)]
+    fused = [t.clone() for t in base]
+    draw_heatmap_multiscale(fused, crb, brb, strides, 6.0, 0.8, clear=clear)
+    for i, s in enumerate(strides):
+        ci, ri = get_centers_and_radii(crb, brb, s)
+        ref = base[i].clone()
+        draw_heatmap_batched(ref, ci, ri, 6.0, 0.8, clear=clear)
+        assert torch.equal(fused[i], ref), f"stride {s}: fused result differs from the per-scale operators"
+        want = base[i].cpu().numpy().copy()
+        oracle.draw_heatmap_batched(want, ci.tensor.cpu().numpy(), ri.tensor.cpu().numpy(),
+                                    crb.sample_sizes.cpu().numpy(), k=0.8, clear=clear)
+        assert np.abs(fused[i].cpu().numpy() - want).max() <= 1e-5
+
+
+def test_multiscale_fallback_shapes_and_validation():
+    from accvlab.draw_heatmap import draw_heatmap_batched, draw_heatmap_multiscale, get_centers_and_radii
+
+    b = 3
+    crb, brb = _objects(b, 10, 300, 200, seed=9)
+    # a width that is not a multiple of 4 and five scales: python falls back to the per-scale operators
+    strides = (2.0, 3.0, 4.0, 5.0, 7.0)
+    maps = [torch.zeros(b, int(200 / s), int(300 / s), device=DEV) for s in strides]
+    draw_heatmap_multiscale(maps, crb, brb, strides, clear=True)
+    for hm, s in zip(maps, strides):
+        ci, ri = get_centers_and_radii(crb, brb, s)
+        ref = torch.empty_like(hm)
+        draw_heatmap_batched(ref, ci, ri, clear=True)
+        assert torch.equal(hm, ref)
+    with pytest.raises(RuntimeError):
+        draw_heatmap_multiscale(maps[:2], crb, brb, (2.0,))                         # length mismatch
+    with pytest.raises(RuntimeError):
+        draw_heatmap_multiscale([maps[0].double()], crb, brb, (2.0,))               # dtype
+    with pytest.raises(RuntimeError):
+        draw_heatmap_multiscale([maps[0][:2]], crb, brb, (2.0,))                    # batch mismatch
+    # no objects at all + clear -> zeros
+    from accvlab.batching_helpers import combine_data
+    empty_c = combine_data([torch.zeros(0, 2)] * b, device=DEV)
+    empty_b = combine_data([torch.zeros(0, 4)] * b, device=DEV)
+    hm = torch.full((b, 16, 32), 3.0, device=DEV)
+    draw_heatmap_multiscale([hm], empty_c, empty_b, (4.0,), clear=True)
+    assert (hm == 0).all()
+
+
+def test_multiscale_is_graph_capturable():
+    from accvlab.draw_heatmap import draw_heatmap_multiscale
+
+    crb, brb = _objects(4, 16, 640, 384, seed=3)
+    maps = [torch.zeros(4, 96, 160, device=DEV), torch.zeros(4, 48, 80, device=DEV)]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        draw_heatmap_multiscale(maps, crb, brb, (4.0, 8.0), clear=True)
+    torch.cuda.synchronize()
+    want = [m.clone() for m in maps]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        draw_heatmap_multiscale(maps, crb, brb, (4.0, 8.0), clear=True)
+    for m in maps:
+        m.fill_(7.0)
+    g.replay()
+    torch.cuda.synchronize()
+    for m, w in zip(maps, want):
+        assert torch.equal(m, w)
