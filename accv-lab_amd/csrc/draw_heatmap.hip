@@ -12,6 +12,14 @@
 //   * each pixel is written exactly once with 16-byte stores (fused-clear mode) or read-max-written once
 //     (in-place mode, only tiles that are touched).
 //
+// Kernels in this file (all share locate_tile / cull_round / make_hit):
+//   splat_kernel        the tile kernel above = splat_body<PX,R,CLEAR,SM,WPG,SRC=0> (headline: <4,8,true,4,1>)
+//   splat_multi_kernel  the same body over the tiles of up to four scales in one launch, objects given as float
+//                       centres / boxes and converted per scale inside the cull (SRC=1)
+//   splat_small_kernel  point-like objects (ACCV_HM_SMALL_RADII): tile in LDS, lanes walk each hit's box, ds_max_f32
+//   bin_* kernels       flat API: counting sort of the objects by plane into plane-sorted copies
+//   targets_from_*      float boxes / sampled polyline points -> integer centre + radius
+//
 // Replaces: packages/draw_heatmap/accvlab/draw_heatmap/include/draw_heatmap_cuda_kernel.cuh:26-108 and
 // csrc/draw_heatmap_cuda.cu:29-165 of the reference (one thread per object, serial atomicMax splat).
 // Plane offsets are 64-bit (the reference's are int and overflow for class-wise full-HD batches).
