@@ -60,6 +60,61 @@ def cpu_baseline(centers_l, radii_l, batch):
                       f"{dt:.2f} s wall = {dt * cores:.0f} core-seconds, OpenMP over frames"}
 
 
+def device_env(dev_index):
+    """Clock / power / partition state of the GPU from sysfs (plain file reads: no child process), sampled while the
+    queue is full.  Boxes of the pool differ by up to 13 % on this kernel; this records what the box looked like."""
+    import glob
+
+    def read(path):
+        try:
+            with open(path) as fh:
+                return fh.read().strip()
+        except OSError:
+            return None
+
+    def current(path):  # pp_dpm_* files list the levels, the active one is starred
+        txt = read(path)
+        if not txt:
+            return None
+        for line in txt.splitlines():
+            if line.rstrip().endswith("*"):
+                return line.split(":", 1)[-1].replace("*", "").strip()
+        return None
+
+    env = {}
+    try:
+        props = torch.cuda.get_device_properties(dev_index)
+        env["name"] = props.name
+        base = None
+        bus = getattr(props, "pci_bus_id", None)
+        if bus is not None:
+            cand = glob.glob(f"/sys/bus/pci/devices/{getattr(props, 'pci_domain_id', 0):04x}:{bus:02x}:"
+                             f"{getattr(props, 'pci_device_id', 0):02x}.0")
+            base = cand[0] if cand else None
+        if base is None:
+            cards = [c for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")) if read(c + "/vendor") == "0x1002"]
+            base = cards[dev_index] if dev_index < len(cards) else (cards[0] if cards else None)
+        if base:
+            for key, f in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk"), ("fclk", "pp_dpm_fclk")):
+                v = current(f"{base}/{f}")
+                if v:
+                    env[key] = v
+            for key, f in (("compute_partition", "current_compute_partition"),
+                           ("memory_partition", "current_memory_partition")):
+                v = read(f"{base}/{f}")
+                if v:
+                    env[key] = v
+            for hw in glob.glob(f"{base}/hwmon/hwmon*"):
+                for key, f, scale in (("power_w", "power1_average", 1e-6), ("power_w", "power1_input", 1e-6),
+                                      ("power_cap_w", "power1_cap", 1e-6)):
+                    v = read(f"{hw}/{f}")
+                    if v and v.isdigit() and key not in env:
+                        env[key] = round(int(v) * scale, 1)
+    except Exception as e:  # noqa: BLE001 - diagnostics only
+        env["error"] = str(e)
+    return env
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,9 +170,12 @@ def main():
     # settle (profiles/r01_rocprof: 109 -> 128 -> 97 us); keep the queue full for >= 100 ms before timing
     torch.cuda.synchronize()
     t_pre = time.perf_counter()
+    env = None
     while time.perf_counter() - t_pre < 0.1:
         for _ in range(50):
             step()
+        if env is None and rank == 0 and time.perf_counter() - t_pre > 0.05:
+            env = device_env(dev_index)     # sampled under load, outside the timed region
         torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
@@ -190,6 +248,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "splat_kernel<4, 8, true, 4, 1> (PX=4, R=8, fused clear, sc1+nt stores, 1 wave/WG)", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
         "secondary": extra,
+        "device": env or {},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(centers_l, radii_l, B)
