@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import functools
 import struct
-from typing import Optional, Sequence
+from typing import Optional
 
 import torch
 
@@ -20,11 +20,6 @@ from .. import _amd_native as _nat
 _COPY_DTYPES = {torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.int32, torch.int64}
 _ACC_CODE = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3, torch.float16: 4, torch.bfloat16: 5}
 _INDEX_DTYPES = (torch.int32, torch.int64)
-
-
-def _req(cond: bool, msg: str) -> None:
-    if not cond:
-        raise RuntimeError(msg)
 
 
 def _contig(t: torch.Tensor, name: str) -> None:

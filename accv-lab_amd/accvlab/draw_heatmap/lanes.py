@@ -17,7 +17,7 @@ import torch
 
 from .. import _amd_native as _nat
 from ..lane_helpers.polyline import ops as _poly
-from .ops import _require, draw_heatmap_batched
+from .ops import draw_heatmap_batched
 
 _cache: dict = {}
 
