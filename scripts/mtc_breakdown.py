@@ -37,6 +37,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tensors", type=int, default=10_000)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--background", action="store_true", help="run the orchestration on the pool thread (the default mode)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     tree = wl.meta_tensor_tree(a.tensors, seed=0)
@@ -70,14 +71,14 @@ def main():
     for m in ("classify", "make_packed_views", "rebuild"):
         wrap(tree_cls, m, f"tree.{m}")
     for _ in range(5):
-        copier.start_copy(tree, dev, use_background_thread=False).get()
+        copier.start_copy(tree, dev, use_background_thread=a.background).get()
     torch.cuda.synchronize()
     acc.clear()
     t_total = 0.0
     t_get = 0.0
     for _ in range(a.iters):
         t0 = time.perf_counter()
-        h = copier.start_copy(tree, dev, use_background_thread=False)
+        h = copier.start_copy(tree, dev, use_background_thread=a.background)
         t1 = time.perf_counter()
         h.get()
         torch.cuda.synchronize()
@@ -88,7 +89,7 @@ def main():
     out["start_copy+get total ms"] = round(t_total / a.iters * 1e3, 4)
     out["get() (wait + rebuild) ms"] = round(t_get / a.iters * 1e3, 4)
     copier._nat.lib = nat_lib_orig
-    print(json.dumps({"tensors": a.tensors, **out}, indent=1))
+    print(json.dumps({"tensors": a.tensors, "background": a.background, **out}, indent=1))
 
 
 if __name__ == "__main__":
