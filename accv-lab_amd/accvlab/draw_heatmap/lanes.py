@@ -93,3 +93,86 @@ def draw_polylines_batched(heatmap: torch.Tensor, polylines: torch.Tensor, num_s
     draw_heatmap_batched(heatmap, SimpleNamespace(tensor=centers, sample_sizes=sizes),
                          SimpleNamespace(tensor=radii, sample_sizes=sizes), diameter_to_sigma_factor, k_scale,
                          clear=clear, small_radii=radius <= 7)
+
+
+def sample_lanes(polylines: torch.Tensor, num_samples: int, *, num_points: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Arc-length-uniform samples of ``polylines`` f32 ``[B, L, P, 2]`` -> f32 ``[B, L * num_samples, 2]`` (source
+    pixels; samples of empty lanes are NaN).  One launch of the polyline sampler."""
+    if not (isinstance(polylines, torch.Tensor) and polylines.is_cuda):
+        raise RuntimeError("polylines must be a CUDA tensor")
+    if not (polylines.dim() == 4 and polylines.size(3) == 2):
+        raise RuntimeError("polylines must be of shape [batch, lanes, points, 2]")
+    if not (polylines.dtype == torch.float32):
+        raise RuntimeError(f"polylines: expected float32 but found {polylines.dtype}")
+    if not (num_samples >= 1):
+        raise RuntimeError("num_samples must be >= 1")
+    b, l, p, _ = polylines.shape
+    dev = polylines.device
+    if b * l == 0:
+        return torch.empty((b, l * num_samples, 2), dtype=torch.float32, device=dev)
+    counts = None
+    if num_points is not None:
+        if not (num_points.shape == (b, l) and num_points.device == dev):
+            raise RuntimeError("num_points must be of shape [batch, lanes] on the polylines' device")
+        _poly._check_sizes(num_points.reshape(-1), p, "num_points")
+        counts = num_points.contiguous().view(b * l)
+    frac = _cached(("frac", b * l, num_samples, dev), lambda: torch.linspace(
+        0.0, 1.0, num_samples, device=dev).unsqueeze(0).expand(b * l, num_samples).contiguous()
+        if num_samples > 1 else torch.zeros((b * l, 1), device=dev))
+    samples = _poly._gpu(polylines.contiguous().view(b * l, p, 2), frac, counts, None, True, True, False)[0]
+    return samples.view(b, l * num_samples, 2)
+
+
+def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: int, radius: int, out_size_factors,
+                              diameter_to_sigma_factor: float = 6.0, k_scale: float = 1.0, *,
+                              num_points: Optional[torch.Tensor] = None, num_lanes: Optional[torch.Tensor] = None,
+                              clear: bool = False) -> None:
+    """Lane raster at several strides: equivalent to ``draw_polylines_batched(heatmaps[s], polylines, num_samples, radius,
+    out_size_factors[s], ...)`` for every scale, in THREE launches altogether (sampler, group boxes, one splat over the
+    tiles of all scales) instead of three per scale.  The splat culls in two levels — 64 consecutive samples share a
+    bounding box — so a tile only walks the stretches of lane that can reach it.  Always uses the box-walking small-splat
+    arithmetic (meant for radii of a few pixels)."""
+    heatmaps = list(heatmaps)
+    strides = [float(f) for f in out_size_factors]
+    if not (len(heatmaps) == len(strides) and len(heatmaps) >= 1):
+        raise RuntimeError("heatmaps and out_size_factors must have the same, non-zero length")
+    b, l = polylines.shape[:2] if polylines.dim() == 4 else (0, 0)
+    fusable = len(heatmaps) <= 4 and radius >= 0
+    for hm in heatmaps:
+        if not (isinstance(hm, torch.Tensor) and hm.is_cuda and hm.is_contiguous() and hm.dtype == torch.float32):
+            raise RuntimeError("every heatmap must be a contiguous float32 CUDA tensor")
+        if not (hm.dim() == 3 and hm.size(0) == b and hm.device == polylines.device):
+            raise RuntimeError("every heatmap must be of shape [batch_size, height, width] on the polylines' device")
+        fusable = fusable and hm.size(2) % 4 == 0 and hm.data_ptr() % 16 == 0 and hm.size(1) * hm.size(2) * 4 < (1 << 31)
+    if not fusable:
+        for hm, f in zip(heatmaps, strides):
+            draw_polylines_batched(hm, polylines, num_samples, radius, f, diameter_to_sigma_factor, k_scale,
+                                   num_points=num_points, num_lanes=num_lanes, clear=clear)
+        return
+    samples = sample_lanes(polylines, num_samples, num_points=num_points)
+    n = l * num_samples
+    dev = polylines.device
+    if num_lanes is None:
+        sizes = _cached(("full", b, n, dev), lambda: torch.full((b,), n, dtype=torch.int32, device=dev))
+    else:
+        if not (num_lanes.shape == (b,)):
+            raise RuntimeError("num_lanes must be of shape [batch]")
+        sizes = num_lanes.clamp(0, l) * num_samples
+        if sizes.dtype not in (torch.int32, torch.int64):
+            sizes = sizes.to(torch.int64)
+    import ctypes
+
+    lib = _nat.lib()
+    k = len(heatmaps)
+    ptrs = (ctypes.c_void_p * k)(*[hm.data_ptr() for hm in heatmaps])
+    hs = (ctypes.c_int * k)(*[hm.size(1) for hm in heatmaps])
+    ws_ = (ctypes.c_int * k)(*[hm.size(2) for hm in heatmaps])
+    st = (ctypes.c_float * k)(*strides)
+    flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if sizes.dtype == torch.int64 else 0)
+    with _nat.device_guard(dev):
+        nbytes = lib.accv_draw_points_workspace_bytes(b, n)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        status = lib.accv_draw_points_multiscale_f32(
+            ptrs, hs, ws_, st, k, b, samples.data_ptr(), sizes.data_ptr(), n, int(radius),
+            float(diameter_to_sigma_factor), float(k_scale), flags, work.data_ptr(), nbytes, _nat.stream_ptr(dev))
+    _nat.check(status, "draw_polylines_multiscale")

@@ -56,6 +56,9 @@ struct SplatParams {
     const float* centers_f;  // [B, n_max, 2] (x, y)
     const float* boxes_f;    // [B, n_max, 4] (x0, y0, x1, y1)
     float stride;
+    // point splats (SRC == 2): centers_f = sampled points [B, n_max, 2]; boxes_f = bounding boxes of every 64 consecutive
+    // points [B, n_groups, 4] (xmin, ymin, xmax, ymax; source pixels); every point gets the same radius
+    int radius, n_groups;
 };
 
 constexpr int kMaxScales = 4;
@@ -109,6 +112,7 @@ struct TileCtx {
     const float2* centers_f;  // SRC == 1: float objects of this plane
     const float4* boxes_f;
     float stride;
+    int radius;              // SRC == 2: the radius of every point
     int n, cls;              // cls < 0: no class filter
 };
 
@@ -157,8 +161,9 @@ __device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, Tile
     t.radii = p.radii + obj_base;
     t.labels = p.labels + obj_base;
     t.centers_f = reinterpret_cast<const float2*>(p.centers_f) + obj_base;
-    t.boxes_f = reinterpret_cast<const float4*>(p.boxes_f) + obj_base;
+    t.boxes_f = reinterpret_cast<const float4*>(p.boxes_f) + (p.n_groups > 0 ? (t.plane * p.n_groups) : obj_base);
     t.stride = p.stride;
+    t.radius = p.radius;
     return true;
 }
 
@@ -183,6 +188,12 @@ __device__ __forceinline__ Cand cull_load(const TileCtx& t, int base, int lane)
         int r = (int)ceilf(__fdiv_rn(m, t.stride));
         if (r < 1) r = 1;
         return Cand{(int)__fdiv_rn(c.x, t.stride), (int)__fdiv_rn(c.y, t.stride), r, 0};
+    } else if constexpr (SRC == 2) {
+        // sampled polyline point -> target of the common radius, exactly targets_from_points_kernel below
+        const float2 c = t.centers_f[cc];
+        const bool bad = (c.x != c.x) || (c.y != c.y);
+        if (bad) return Cand{0, 0, -1, 0};
+        return Cand{(int)__fdiv_rn(c.x, t.stride), (int)__fdiv_rn(c.y, t.stride), t.radius, 0};
     } else {
         const int2 cxy = t.centers2[cc];
         return Cand{cxy.x, cxy.y, t.radii[cc], t.labels[cc]};
@@ -380,8 +391,8 @@ __global__ __launch_bounds__(64) void splat_multi_kernel(const MultiParams mp)
 // hit, lets 16 lanes walk the pixels of the hit's clipped box only: v = k * exp2(-(dx^2 + dy^2) c), one LDS float-max
 // atomic (ds_max_f32) per box pixel, four hits in flight per wave.  Correct for any radius, but only faster below ~15x15 boxes; the host selects it on the
 // caller's ACCV_HM_SMALL_RADII hint.  Same culling, same store path, same clear / in-place semantics.
-template <bool CLEAR, int SM>
-__global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
+template <bool CLEAR, int SM, int SRC>
+__device__ __forceinline__ void small_body(const SplatParams& p, long long linear_group)
 {
     constexpr int TW = 128, TH = 16;
     __shared__ Hit s_hit[kCand];
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
 
     const int lane = threadIdx.x & 63;
     TileCtx t;
-    if (!locate_tile<TW, TH, 1>(p, 0, t, blockIdx.x)) return;
+    if (!locate_tile<TW, TH, 1>(p, 0, t, linear_group)) return;
     const int sub = lane >> 5, col0 = t.tx0 + (lane & 31) * 4;
 
     // "untouched" is -inf in the LDS tile (fused-clear mode starts from 0 = the cleared map)
@@ -401,50 +412,98 @@ __global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile initialised before the first atomic
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // long object lists are the normal case here (10^3 lane samples per plane) and the wave needs few registers, so
-    // the candidate loads of kFetch rounds are issued together: one memory round trip per kFetch * 64 candidates
-    constexpr int kFetch = 4;
     int total_hits = 0;
-    for (int base = 0; base < t.n; base += kFetch * kCand) {
-        Cand cand[kFetch];
-#pragma unroll
-        for (int u = 0; u < kFetch; ++u) cand[u] = cull_load(t, base + u * kCand, lane);
-#pragma unroll
-        for (int u = 0; u < kFetch; ++u) {
-            const int sub_base = base + u * kCand;
-            if (sub_base >= t.n) break;
-            const unsigned long long m = cull_test(t, sub_base, lane, cand[u]);
-            const int nh = __popcll(m);
-            if (nh == 0) continue;
-            if ((m >> lane) & 1ull)
-                s_hit[__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, cand[u].x, cand[u].y, cand[u].r);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // four hits at a time, 16 lanes per hit walking its box.  Pixel updates are LDS float-max atomics
-            // (ds_max_f32, no return value): they commute, so neither overlapping boxes of concurrent hits nor
-            // successive hits need any ordering — the wave just streams them
-            const int grp = lane >> 4, l16 = lane & 15;
-            for (int h0 = 0; h0 < nh; h0 += 4) {
-                const int h = h0 + grp;
-                if (h >= nh) continue;
-                const Hit hh = s_hit[h];
-                const int xlo = hh.box & 255u, xhi = (hh.box >> 8) & 255u, ylo = (hh.box >> 16) & 255u, yhi = hh.box >> 24;
-                const int w = xhi - xlo, area = w * (yhi - ylo);  // 0 for an empty box
-                const float inv_w = 1.0f / (float)max(w, 1);
-                for (int q = l16; q < area; q += 16) {
-                    // q / w for q < 2048, w <= 128: (q + 0.5) / w is at least 1/256 away from an integer, far more
-                    // than the error of the reciprocal
-                    const int py = (int)(((float)q + 0.5f) * inv_w);
-                    const int px = q - py * w;
-                    const float dx = (float)(t.tx0 + xlo + px - hh.x), dy = (float)(t.ty0 + ylo + py - hh.y);
-                    const float v = p.k * raw_exp2(-(dx * dx + dy * dy) * hh.c2);
-                    __hip_atomic_fetch_max(&s_tile[ylo + py][xlo + px], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    // one cull round over the 64 candidates [sub_base, sub_base + 64): compaction, then the hits' boxes are walked
+    auto process_round = [&](int sub_base, const Cand& cand) {
+        const unsigned long long m = cull_test(t, sub_base, lane, cand);
+        const int nh = __popcll(m);
+        if (nh == 0) return;
+        if ((m >> lane) & 1ull) s_hit[__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, cand.x, cand.y, cand.r);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // four hits at a time, 16 lanes per hit walking its box.  Pixel updates are LDS float-max atomics
+        // (ds_max_f32, no return value): they commute, so neither overlapping boxes of concurrent hits nor
+        // successive hits need any ordering — the wave just streams them
+        const int grp = lane >> 4, l16 = lane & 15;
+        for (int h0 = 0; h0 < nh; h0 += 4) {
+            const int h = h0 + grp;
+            if (h >= nh) continue;
+            const Hit hh = s_hit[h];
+            const int xlo = hh.box & 255u, xhi = (hh.box >> 8) & 255u, ylo = (hh.box >> 16) & 255u, yhi = hh.box >> 24;
+            const int w = xhi - xlo, area = w * (yhi - ylo);  // 0 for an empty box
+            const float inv_w = 1.0f / (float)max(w, 1);
+            for (int q = l16; q < area; q += 16) {
+                // q / w for q < 2048, w <= 128: (q + 0.5) / w is at least 1/256 away from an integer, far more
+                // than the error of the reciprocal
+                const int py = (int)(((float)q + 0.5f) * inv_w);
+                const int px = q - py * w;
+                const float dx = (float)(t.tx0 + xlo + px - hh.x), dy = (float)(t.ty0 + ylo + py - hh.y);
+                const float v = p.k * raw_exp2(-(dx * dx + dy * dy) * hh.c2);
+                __hip_atomic_fetch_max(&s_tile[ylo + py][xlo + px], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        // the next round overwrites the hit list: order it behind this round's reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        total_hits += nh;
+    };
+
+    if constexpr (SRC == 2) {
+        // two-level cull: consecutive polyline samples are neighbours in space, so each group of 64 carries a
+        // bounding box (group_boxes_kernel); a lane tests one GROUP, and only groups that can reach the tile are
+        // walked candidate by candidate — a tile crossed by a lane visits 1-3 rounds instead of all of them
+        constexpr float kClampF = 536870912.0f;  // 2^29, as in the integer cull
+        for (int g0 = 0; g0 < p.n_groups; g0 += kCand) {
+            const int g = g0 + lane;
+            bool ghit = false;
+            if (g < p.n_groups && g * kCand < t.n) {
+                const float4 b = t.boxes_f[g];
+                if (b.x <= b.z) {  // not empty (a group of NaN points keeps xmin = +inf)
+                    const int cx0 = (int)fminf(fmaxf(__fdiv_rn(b.x, t.stride), -kClampF), kClampF);
+                    const int cy0 = (int)fminf(fmaxf(__fdiv_rn(b.y, t.stride), -kClampF), kClampF);
+                    const int cx1 = (int)fminf(fmaxf(__fdiv_rn(b.z, t.stride), -kClampF), kClampF);
+                    const int cy1 = (int)fminf(fmaxf(__fdiv_rn(b.w, t.stride), -kClampF), kClampF);
+                    const int rc = min(max(t.radius, 0), 1 << 30);
+                    ghit = cx0 - rc < t.tx1 && cx1 + rc >= t.tx0 && cy0 - rc < t.ty1 && cy1 + rc >= t.ty0;
                 }
             }
-            // the next sub-round overwrites the hit list: order it behind this round's reads
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            total_hits += nh;
+            unsigned long long mg = __ballot(ghit);
+            while (mg) {  // wave-uniform; the candidates of up to four groups are fetched together (one round trip)
+                constexpr int kFetch = 4;
+                int sub_base[kFetch];
+                Cand cand[kFetch];
+#pragma unroll
+                for (int u = 0; u < kFetch; ++u) {
+                    sub_base[u] = -1;
+                    if (mg) {
+                        sub_base[u] = (g0 + __builtin_ctzll(mg)) * kCand;
+                        mg &= mg - 1;
+                        cand[u] = cull_load<2>(t, sub_base[u], lane);
+                        // consecutive samples that land on the same pixel are one and the same splat (coarse scales see
+                        // several samples per pixel): keep the first of a run, results are unchanged
+                        const int nx = __shfl_up(cand[u].x, 1), ny = __shfl_up(cand[u].y, 1), nr = __shfl_up(cand[u].r, 1);
+                        if (lane > 0 && nx == cand[u].x && ny == cand[u].y && nr == cand[u].r) cand[u].r = -1;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kFetch; ++u)
+                    if (sub_base[u] >= 0) process_round(sub_base[u], cand[u]);
+            }
+        }
+    } else {
+        // long object lists are the normal case here (10^3 lane samples per plane) and the wave needs few registers,
+        // so the candidate loads of kFetch rounds are issued together: one memory round trip per kFetch * 64 candidates
+        constexpr int kFetch = 4;
+        for (int base = 0; base < t.n; base += kFetch * kCand) {
+            Cand cand[kFetch];
+#pragma unroll
+            for (int u = 0; u < kFetch; ++u) cand[u] = cull_load<SRC>(t, base + u * kCand, lane);
+#pragma unroll
+            for (int u = 0; u < kFetch; ++u) {
+                const int sub_base = base + u * kCand;
+                if (sub_base >= t.n) break;
+                process_round(sub_base, cand[u]);
+            }
         }
     }
 
@@ -474,6 +533,50 @@ __global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
             *dst = out;
         }
     }
+}
+
+template <bool CLEAR, int SM>
+__global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
+{
+    small_body<CLEAR, SM, 0>(p, blockIdx.x);
+}
+
+// lane rasters of all scales in one launch: float sample points, two-level cull (SRC = 2), scale from the tile prefix
+template <bool CLEAR, int SM>
+__global__ __launch_bounds__(64) void splat_points_multi_kernel(const MultiParams mp)
+{
+    int s = 0;
+    while (s + 1 < mp.n_scales && (long long)blockIdx.x >= mp.tile_begin[s + 1]) ++s;
+    small_body<CLEAR, SM, 2>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s]);
+}
+
+// bounding box (xmin, ymin, xmax, ymax) of every 64 consecutive points of points[b, :, :] (NaN points ignored; a group
+// without valid points keeps xmin = +inf > xmax = -inf): one wave per group
+__global__ __launch_bounds__(64) void group_boxes_kernel(const float2* __restrict__ points, int num_points, int n_groups,
+                                                         long long total_groups, float4* __restrict__ boxes)
+{
+    const long long gid = blockIdx.x;
+    if (gid >= total_groups) return;
+    const long long b = gid / n_groups;
+    const int g = (int)(gid - b * n_groups);
+    const int i = g * 64 + (int)threadIdx.x;
+    const float inf = __builtin_inff();
+    float x0 = inf, y0 = inf, x1 = -inf, y1 = -inf;
+    if (i < num_points) {
+        const float2 c = points[b * num_points + i];
+        if (c.x == c.x && c.y == c.y) {
+            x0 = x1 = c.x;
+            y0 = y1 = c.y;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, d));
+        y0 = fminf(y0, __shfl_xor(y0, d));
+        x1 = fmaxf(x1, __shfl_xor(x1, d));
+        y1 = fmaxf(y1, __shfl_xor(y1, d));
+    }
+    if (threadIdx.x == 0) boxes[gid] = make_float4(x0, y0, x1, y1);
 }
 
 int launch_splat_small(SplatParams p, long long planes, bool clear, int sm, hipStream_t stream)
@@ -906,6 +1009,100 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
             hipLaunchKernelGGL((splat_multi_kernel<false, 0>), grid, block, 0, stream, mp);
     }
     return accv::check_launch("draw_heatmap multi-scale splat kernel");
+}
+
+size_t accv_draw_points_workspace_bytes(int batch, int num_points)
+{
+    if (batch < 0 || num_points < 0) return 0;
+    return (size_t)batch * (size_t)((num_points + 63) / 64) * sizeof(float4) + 16;
+}
+
+int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, const int* widths, const float* strides,
+                                    int num_scales, int batch, const float* points_xy, const void* counts, int num_points,
+                                    int radius, float diameter_to_sigma_factor, float k_scale, unsigned flags,
+                                    void* workspace, size_t workspace_bytes, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (num_scales < 1 || num_scales > kMaxScales)
+        return accv::fail(ACCV_EINVAL, "draw_points_multiscale: 1..%d scales supported, got %d", kMaxScales, num_scales);
+    if (!heatmaps || !heights || !widths || !strides) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: null array");
+    if (batch < 0 || num_points < 0) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: negative count");
+    if (num_points > (1 << 30)) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: more than 2^30 points per sample");
+    if (batch == 0) return ACCV_OK;
+    if (!counts) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: counts pointer is null");
+    if (num_points > 0 && !points_xy) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: null point array");
+    if (reinterpret_cast<uintptr_t>(points_xy) & 7u)
+        return accv::fail(ACCV_EINVAL, "draw_points_multiscale: points need 8-byte alignment");
+    const bool clear = (flags & ACCV_HM_CLEAR) != 0;
+    if (num_points == 0 && !clear) return ACCV_OK;
+    const size_t need = accv_draw_points_workspace_bytes(batch, num_points);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15u))
+        return accv::fail(ACCV_EWORKSPACE, "draw_points_multiscale: workspace needs %zu aligned bytes, got %zu", need,
+                          workspace_bytes);
+    const int n_groups = (num_points + 63) / 64;
+
+    MultiParams mp{};
+    long long tiles = 0;
+    size_t total_bytes = 0;
+    int used = 0;
+    for (int i = 0; i < num_scales; ++i) {
+        if (int rc = check_common(heatmaps[i], heights[i], widths[i], diameter_to_sigma_factor, "draw_points_multiscale"))
+            return rc;
+        if (!(strides[i] > 0.0f)) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: stride %d is not positive", i);
+        if (heights[i] == 0 || widths[i] == 0) continue;
+        if (!heatmaps[i]) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: heatmap %d is null", i);
+        if (widths[i] % 4 != 0 || (reinterpret_cast<uintptr_t>(heatmaps[i]) & 15u) ||
+            (size_t)heights[i] * widths[i] * sizeof(float) >= ((size_t)1 << 31))
+            return accv::fail(ACCV_EINVAL, "draw_points_multiscale: map %d needs a width that is a multiple of 4, a 16-byte "
+                                           "aligned base and planes below 2 GiB (use the per-scale calls otherwise)", i);
+        SplatParams& p = mp.scale[used];
+        p.hm = heatmaps[i];
+        p.counts = counts;
+        p.H = heights[i];
+        p.W = widths[i];
+        p.n_max = num_points;
+        p.factor = diameter_to_sigma_factor;
+        p.k = k_scale;
+        p.counts_i64 = (flags & ACCV_HM_COUNTS_I64) ? 1 : 0;
+        p.centers_f = points_xy;
+        p.boxes_f = static_cast<const float*>(workspace);
+        p.stride = strides[i];
+        p.radius = radius;
+        p.n_groups = n_groups;
+        p.tiles_x = (p.W + 127) / 128;
+        p.tiles_y = (p.H + 15) / 16;
+        p.n_tiles = (long long)batch * p.tiles_x * p.tiles_y;
+        p.grid3d = 0;
+        mp.tile_begin[used] = tiles;
+        tiles += p.n_tiles;
+        total_bytes += (size_t)batch * p.H * p.W * sizeof(float);
+        ++used;
+    }
+    mp.n_scales = used;
+    mp.tile_begin[used] = tiles;
+    if (used == 0 || tiles == 0) return ACCV_OK;
+    if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: %lld tiles exceed the grid limit", tiles);
+    const long long total_groups = (long long)batch * n_groups;
+    if (total_groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: too many point groups");
+    if (total_groups > 0)
+        hipLaunchKernelGGL(group_boxes_kernel, dim3((unsigned)total_groups), dim3(64), 0, stream,
+                           reinterpret_cast<const float2*>(points_xy), num_points, n_groups, total_groups,
+                           static_cast<float4*>(workspace));
+    int nt = accv::tune_get("hm_nt", -1);
+    if (nt < 0) nt = total_bytes > ((size_t)128 << 20) ? 4 : 0;
+    const dim3 grid((unsigned)tiles), block(64);
+    if (clear) {
+        if (nt >= 2)
+            hipLaunchKernelGGL((splat_points_multi_kernel<true, 4>), grid, block, 0, stream, mp);
+        else
+            hipLaunchKernelGGL((splat_points_multi_kernel<true, 0>), grid, block, 0, stream, mp);
+    } else {
+        if (nt >= 2)
+            hipLaunchKernelGGL((splat_points_multi_kernel<false, 4>), grid, block, 0, stream, mp);
+        else
+            hipLaunchKernelGGL((splat_points_multi_kernel<false, 0>), grid, block, 0, stream, mp);
+    }
+    return accv::check_launch("draw_heatmap multi-scale point splat kernel");
 }
 
 int accv_heatmap_targets_from_boxes_f32(const float* centers_xy, const float* boxes_xyxy, long long num_objects,

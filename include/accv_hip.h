@@ -76,6 +76,20 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
                                      const void* counts, int max_num_targets, float diameter_to_sigma_factor,
                                      float k_scale, unsigned flags, void* stream);
 
+/* Lane raster of all scales in TWO launches (BASELINE config 3): sampled polyline points f32[batch, N, 2]
+ * (source pixels; output of accv_polyline_sample, NaN = sample of an empty polyline) are drawn into every
+ * heatmaps[s] f32[batch, heights[s], widths[s]] as Gaussians of `radius` around int(p / strides[s]) — for each scale the
+ * result of accv_heatmap_targets_from_points_f32 + accv_draw_heatmap_batched_f32 with ACCV_HM_SMALL_RADII.  Launch 1
+ * writes the bounding box of every 64 consecutive points into `workspace` (accv_draw_points_workspace_bytes); launch 2
+ * covers the tiles of all (<= 4) scales and culls first by group box, then by point.  counts[b] (int32, or int64 with
+ * ACCV_HM_COUNTS_I64) = number of leading points of sample b that are drawn.  Same map constraints as the multi-scale
+ * box call.  The reference has no polyline rasteriser (polyline/functions.py:27-111 only samples). */
+size_t accv_draw_points_workspace_bytes(int batch, int num_points);
+int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, const int* widths, const float* strides,
+                                    int num_scales, int batch, const float* points_xy, const void* counts, int num_points,
+                                    int radius, float diameter_to_sigma_factor, float k_scale, unsigned flags,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* Target-prep front end: float centres [n,2] (x,y) and boxes [n,4] (x0,y0,x1,y1) in source pixels ->
  * int32 centres [n,2] = int(c / stride) and radii [n] = max(1, int(ceil(min edge distance / stride))) in ONE kernel.
  * Semantics of get_centers_and_radii (packages/draw_heatmap/tests/_test_helpers.py:20-28; the DALI path uses

@@ -223,6 +223,19 @@ def c3():
             draw_polylines_batched(lm, lanes, 1024 // s, 2, float(s), clear=True)
 
     t2 = _timeit(step_lanes, 50, 500, torch.cuda.synchronize)
+    # everything fused: boxes of all scales in one launch + lanes of all scales in three (one sampling at 256 per lane)
+    from accvlab.draw_heatmap import draw_polylines_multiscale
+
+    def step_all_fused():
+        draw_heatmap_multiscale(maps, crb_f, brb_f, (4.0, 8.0, 16.0), 6.0, 1.0, clear=True)
+        draw_polylines_multiscale(lane_maps, lanes, 256, 2, (4.0, 8.0, 16.0), clear=True)
+
+    t3 = _timeit(step_all_fused, 50, 500, torch.cuda.synchronize)
+    t3l = _timeit(lambda: draw_polylines_multiscale(lane_maps, lanes, 256, 2, (4.0, 8.0, 16.0), clear=True), 50, 500,
+                  torch.cuda.synchronize)
+    print(json.dumps({"config": "C3+lanes fused", "metric": "float boxes + lanes (256 samples per lane at every scale), "
+                      "4 launches per batch of 32", "ms_per_batch": t3 * 1e3, "frames_per_s": B / t3,
+                      "GBps": 2 * nbytes / t3 / 1e9, "lane_raster_only_ms": t3l * 1e3}))
     print(json.dumps({"config": "C3+lanes", "metric": "C3 + lane raster (8 lanes x 24 pts, 256/128/64 samples, r=2) per scale",
                       "ms_per_batch": t2 * 1e3, "frames_per_s": B / t2, "GBps": 2 * nbytes / t2 / 1e9,
                       "bytes_per_frame": 2 * nbytes // B, "lane_part_ms": (t2 - t) * 1e3,

@@ -101,3 +101,49 @@ def test_lane_raster_validation_and_empty():
     draw_polylines_batched(hm, torch.zeros(2, 3, 4, 2, device=dev), 8, 2,
                            num_points=torch.zeros(2, 3, dtype=torch.int32, device=dev))
     assert (hm == 0.25).all()
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+@pytest.mark.parametrize("clear", [True, False])
+@pytest.mark.parametrize("radius,q", [(2, 64), (1, 200), (5, 17)])
+def test_multiscale_lane_raster_equals_per_scale_calls(ragged, clear, radius, q):
+    from accvlab.draw_heatmap import draw_polylines_batched, draw_polylines_multiscale
+
+    dev = torch.device("cuda", 0)
+    b, l, p, sw, sh = 3, 5, 12, 1536.0, 864.0
+    strides = (4.0, 8.0, 16.0)
+    pts, npts, nlanes = _lanes(b, l, p, sw, sh, seed=radius * 100 + q, ragged=ragged)
+    pts_d = torch.from_numpy(pts).to(dev)
+    npts_d = torch.from_numpy(npts).to(dev) if ragged else None
+    nlanes_d = torch.from_numpy(nlanes).to(dev) if ragged else None
+    shapes = [(b, int(sh / s), int(sw / s)) for s in strides]
+    base = [torch.rand(s_, generator=torch.Generator().manual_seed(i)).mul_(0.3).to(dev) for i, s_ in enumerate(shapes)]
+    fused = [t.clone() for t in base]
+    draw_polylines_multiscale(fused, pts_d, q, radius, strides, 6.0, 0.9, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
+    for i, s in enumerate(strides):
+        ref = base[i].clone()
+        draw_polylines_batched(ref, pts_d, q, radius, s, 6.0, 0.9, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
+        assert torch.equal(fused[i], ref), f"stride {s}: fused lane raster differs from the per-scale operator"
+    assert any(bool((f != b_).any()) for f, b_ in zip(fused, base))            # something was drawn
+
+
+def test_multiscale_lane_raster_fallback_and_large_radius():
+    from accvlab.draw_heatmap import draw_polylines_batched, draw_polylines_multiscale
+
+    dev = torch.device("cuda", 0)
+    pts, _, _ = _lanes(2, 3, 9, 400.0, 300.0, seed=5, ragged=False)
+    pts_d = torch.from_numpy(pts).to(dev)
+    # odd widths -> python falls back to the per-scale operator (bit-identical by construction)
+    maps = [torch.zeros(2, 75, 101, device=dev), torch.zeros(2, 37, 50, device=dev)]
+    draw_polylines_multiscale(maps, pts_d, 40, 2, (4.0, 8.0), clear=True)
+    for hm, s in zip(maps, (4.0, 8.0)):
+        ref = torch.empty_like(hm)
+        draw_polylines_batched(ref, pts_d, 40, 2, s, clear=True)
+        assert torch.equal(hm, ref)
+    # a radius above the small-splat hint: the fused op keeps the box-walking arithmetic, the per-scale op switches to
+    # the tile kernel (separable product) -> equal to rounding
+    a = [torch.zeros(2, 76, 100, device=dev)]
+    draw_polylines_multiscale(a, pts_d, 40, 12, (4.0,), clear=True)
+    ref = torch.zeros(2, 76, 100, device=dev)
+    draw_polylines_batched(ref, pts_d, 40, 12, 4.0, clear=True)
+    assert float((a[0] - ref).abs().max()) <= 1e-6
