@@ -110,3 +110,34 @@ def test_polyline_kernel_stays_inside_its_output(P, Q, D):
     torch.cuda.synchronize()
     assert _margins_clean(buf, start, n)
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("clear", [True, False])
+def test_multiscale_kernels_stay_inside_their_maps(clear):
+    from accvlab.batching_helpers import combine_data
+    from accvlab.draw_heatmap import draw_heatmap_multiscale, draw_polylines_multiscale
+
+    b = 3
+    g = torch.Generator().manual_seed(11)
+    cs, bs = [], []
+    for _ in range(b):
+        n = int(torch.randint(0, 12, (1,), generator=g))
+        c = torch.rand(n, 2, generator=g) * torch.tensor([500.0, 300.0])
+        half = torch.rand(n, 4, generator=g) * 60
+        cs.append(c)
+        bs.append(torch.cat([c - half[:, :2], c + half[:, 2:]], 1))
+    crb = combine_data(cs, device=DEV)
+    brb = combine_data(bs, device=DEV, other_with_same_sample_sizes=crb)
+    lanes = (torch.rand(b, 4, 9, 2, generator=g) * torch.tensor([520.0, 320.0]) - 10).to(DEV)   # partly outside
+    shapes = [(b, 75, 128), (b, 37, 64), (b, 19, 32), (b, 9, 16)]       # heights not multiples of 16, widths of 4
+    strides = (4.0, 8.0, 16.0, 32.0)
+    bufs = [_inside(s, pad=256) for s in shapes]                        # 256-float pad keeps the 16-byte alignment
+    for _, view, _, _ in bufs:
+        view.fill_(0.1)
+    maps = [v for _, v, _, _ in bufs]
+    draw_heatmap_multiscale(maps, crb, brb, strides, clear=clear)
+    draw_polylines_multiscale(maps, lanes, 70, 2, strides, clear=False)
+    torch.cuda.synchronize()
+    for (buf, view, start, n), s in zip(bufs, shapes):
+        assert _margins_clean(buf, start, n), f"multi-scale kernels wrote outside the {s} map"
+        assert torch.isfinite(view).all()
