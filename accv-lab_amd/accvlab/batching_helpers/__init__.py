@@ -6,22 +6,25 @@
 tensors use torch.  The reference's private extension modules are available under their original names
 (``batched_indexing_access_cuda``, ``batched_indexing_access_cpu``) with the same functions.
 """
-from .ragged import RaggedBatch
-from .indexing import (
+# Imported through the modules that carry the reference's names (thin aliases of ragged / indexing / bool_indexing /
+# packing), as the reference's own __init__ does: a module and a function share the name `batched_bool_indexing`, and
+# the function must be what the package attribute ends up bound to.
+from .data_format import RaggedBatch
+from .batched_indexing_ops import (
     batched_indexing_access,
     batched_inverse_indexing_access,
     batched_indexing_write,
-    batched_index_mapping,
-    get_mask_from_indices,
 )
-from .bool_indexing import (
+from .batched_index_mapping_op import batched_index_mapping
+from .batched_mask_from_indices import get_mask_from_indices
+from .batched_bool_indexing import (
     batched_bool_indexing,
     batched_bool_indexing_write,
+)
+from .batched_processing_py import (
     get_compact_from_named_tuple,
     get_compact_lists,
     get_indices_from_mask,
-)
-from .packing import (
     average_over_targets,
     sum_over_targets,
     apply_mask_to_tensor,

@@ -19,20 +19,40 @@ def _req(cond, msg):
 
 
 def _check_points(points, name="points"):
+    # messages as check_device / check_type of the reference (ext_impl/polyline/src/polyline.cpp:40-63)
     if not (isinstance(points, torch.Tensor)):
         raise RuntimeError(f"{name} must be a tensor")
     if not (points.device.type in ("cpu", "cuda")):
         raise RuntimeError(f"{name} must be a CPU or CUDA tensor")
-    ok = points.dtype in _DTYPE_CODE if points.is_cuda else points.dtype in (torch.float32, torch.float64)
-    if not (ok):
-        raise RuntimeError(f"{name} has an unsupported dtype {points.dtype}")
+    if points.is_cuda:
+        if points.dtype not in _DTYPE_CODE:
+            raise RuntimeError(f"{name} must have dtype float16, float32, float64, or bfloat16 on CUDA")
+    elif points.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"{name} must have dtype float32 or float64 on CPU")
 
 
 def _check_sizes(sizes, limit, name):
     if not (sizes.dtype in (torch.int32, torch.int64)):
-        raise RuntimeError(f"{name} must be int32 or int64")
+        raise RuntimeError(f"{name} must have dtype int32 or int64")
     if not (sizes.dim() == 1):
         raise RuntimeError(f"{name} must be a 1D tensor")
+
+
+def _check_size_values(checks):
+    """Every count must lie in [0, padded extent] (check_sample_sizes, polyline.cpp:74-81).  The reference reads two
+    flags back per size tensor; here all of a call's size tensors are checked with ONE read-back (none for CPU tensors
+    beyond the comparison itself).  The kernels clamp anyway, so internal callers that build the counts themselves
+    (accvlab.draw_heatmap.lanes) skip this."""
+    bad = None
+    for sizes, limit, _ in checks:
+        if sizes.numel():
+            b = ((sizes < 0) | (sizes > limit)).any()
+            bad = b if bad is None else (bad | b.to(bad.device))
+    if bad is None or not bool(bad):
+        return
+    for sizes, limit, name in checks:
+        if sizes.numel() and bool(((sizes < 0) | (sizes > limit)).any()):
+            raise RuntimeError(f"{name} values must be in [0, {limit}]")
 
 
 def _gpu(points, distances, p_sizes, d_sizes, relative, want_points, want_lengths):
@@ -184,6 +204,7 @@ def interpolate_var_size_batch(points, distances, *, relative: bool = False):
                                "(both int32 or both int64)")
     _check_var(pt, ps, "points.sample_sizes")
     _check_var(dt, ds, "distances.sample_sizes")
+    _check_size_values([(ps, pt.size(1), "points.sample_sizes"), (ds, dt.size(1), "distances.sample_sizes")])
     if pt.is_cuda:
         res = _gpu(pt, dt, ps, ds, relative, True, False)[0]
     else:
@@ -200,6 +221,7 @@ def lengths_var_size_batch(points) -> torch.Tensor:
     if not (pt.dim() == 3):
         raise RuntimeError("points must have shape (batch, max_num_points, num_dims)")
     _check_var(pt, ps, "points.sample_sizes")
+    _check_size_values([(ps, pt.size(1), "points.sample_sizes")])
     if pt.is_cuda:
         return _gpu(pt, None, ps, None, False, False, True)[1]
     return _cpu_lengths(pt, ps)
