@@ -97,3 +97,28 @@ def test_multiscale_is_graph_capturable():
     torch.cuda.synchronize()
     for m, w in zip(maps, want):
         assert torch.equal(m, w)
+
+
+def test_extension_module_entry_points_match_the_public_operators():
+    # accvlab.draw_heatmap.draw_heatmap_ext: the names of the reference's compiled module (csrc/draw_heatmap.cpp:131-144)
+    from types import SimpleNamespace
+
+    from accvlab.draw_heatmap import draw_heatmap_batched
+    from accvlab.draw_heatmap import draw_heatmap_ext as ext
+
+    g = torch.Generator().manual_seed(2)
+    b, n, c, h, w = 3, 7, 4, 40, 64
+    centers = torch.stack([torch.randint(0, w, (b, n), generator=g), torch.randint(0, h, (b, n), generator=g)], -1)
+    centers = centers.to(torch.int32).to(DEV)
+    radii = torch.randint(1, 9, (b, n), generator=g).to(torch.int32).to(DEV)
+    labels = torch.randint(0, c, (b, n), generator=g).to(torch.int32).to(DEV)
+    counts = torch.tensor([7, 0, 3], dtype=torch.int32, device=DEV)
+    rb = lambda t: SimpleNamespace(tensor=t, sample_sizes=counts)  # noqa: E731
+    a, ref = torch.zeros(b, h, w, device=DEV), torch.zeros(b, h, w, device=DEV)
+    ext.draw_heatmap_batched_impl(a, centers, radii, counts, 6.0, 0.7)
+    draw_heatmap_batched(ref, rb(centers), rb(radii), 6.0, 0.7)
+    assert torch.equal(a, ref) and float(a.max()) > 0
+    a, ref = torch.zeros(b, c, h, w, device=DEV), torch.zeros(b, c, h, w, device=DEV)
+    ext.draw_heatmap_batched_classwise_impl(a, centers, radii, counts, labels, 6.0, 0.7)
+    draw_heatmap_batched(ref, rb(centers), rb(radii), 6.0, 0.7, rb(labels))
+    assert torch.equal(a, ref) and float(a.max()) > 0
