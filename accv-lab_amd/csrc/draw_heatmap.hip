@@ -746,11 +746,12 @@ __global__ __launch_bounds__(1024) void bin_small_kernel(const int32_t* __restri
     }
 }
 
-__global__ void fill_kernel(float4* __restrict__ dst, size_t n4, float value)
+// ONE 16-byte store per thread: waves that issue a single store stream at ~7 TB/s, a grid-stride loop (several stores
+// per wave) at 4.3-5.9 TB/s on the same boxes (profiles/r01_fill_patterns*.log)
+__global__ __launch_bounds__(256) void fill_kernel(float4* __restrict__ dst, size_t n4, float value)
 {
-    const float4 v = make_float4(value, value, value, value);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
-        dst[i] = v;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) dst[i] = make_float4(value, value, value, value);
 }
 __global__ void fill_tail_kernel(float* __restrict__ dst, size_t n, float value)
 {
@@ -1148,9 +1149,11 @@ int accv_fill_f32(float* dst, size_t count, float value, void* stream_)
     while (((reinterpret_cast<uintptr_t>(dst + head)) & 15u) && head < count) ++head;
     if (head) hipLaunchKernelGGL(fill_tail_kernel, dim3(1), dim3(64), 0, stream, dst, head, value);
     const size_t n4 = (count - head) / 4;
-    if (n4) {
-        const unsigned blocks = (unsigned)min((n4 + 255) / 256, (size_t)256 * 16);
-        hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<float4*>(dst + head), n4, value);
+    for (size_t done = 0; done < n4;) {  // one launch unless the buffer has more than 2^31 * 256 vectors
+        const size_t part = std::min(n4 - done, (size_t)0x7fffffff * 256);
+        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<float4*>(dst + head) + done, part, value);
+        done += part;
     }
     const size_t tail = count - head - n4 * 4;
     if (tail) hipLaunchKernelGGL(fill_tail_kernel, dim3(1), dim3(64), 0, stream, dst + head + n4 * 4, tail, value);

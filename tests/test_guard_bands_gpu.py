@@ -141,3 +141,15 @@ def test_multiscale_kernels_stay_inside_their_maps(clear):
     for (buf, view, start, n), s in zip(bufs, shapes):
         assert _margins_clean(buf, start, n), f"multi-scale kernels wrote outside the {s} map"
         assert torch.isfinite(view).all()
+
+
+@pytest.mark.parametrize("count,offset", [(0, 0), (1, 0), (3, 1), (4, 0), (1023, 3), (1 << 20, 0), ((1 << 20) + 5, 2)])
+def test_fill_f32_fills_exactly_its_range(count, offset):
+    from accvlab import _amd_native as nat
+
+    buf, view, start, n = _inside((max(count, 1),), offset=offset)
+    view.fill_(1.0)
+    nat.check(nat.lib().accv_fill_f32(view.data_ptr(), count, 2.5, nat.stream_ptr(DEV)), "fill")
+    torch.cuda.synchronize()
+    assert _margins_clean(buf, start, n)
+    assert bool((view[:count] == 2.5).all()) and bool((view[count:] == 1.0).all())
