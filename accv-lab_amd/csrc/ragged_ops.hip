@@ -260,6 +260,43 @@ __global__ __launch_bounds__(256) void mask_to_indices_kernel(const uint8_t* __r
 }
 
 // ---- flat -> padded pack: dst[i, j, :] = flat[offsets[i] + j, :] (j < sizes[i]); padding gets `pattern`
+// wide rows: one WORKGROUP of NW waves per row, NW*64 mask bytes per step; the waves' hit counts meet in LDS (double
+// buffered: one barrier per step) so that the order-preserving offsets stay exact
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mask_to_indices_block_kernel(const uint8_t* __restrict__ mask,
+                                                                        const void* __restrict__ valid, int valid_i64,
+                                                                        long long width, long long* __restrict__ out_idx,
+                                                                        long long* __restrict__ out_sizes)
+{
+    __shared__ int s_cnt[2][NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long row = blockIdx.x;
+    long long limit = width;
+    if (valid) limit = max(0ll, min(width, load_int(valid, row, valid_i64)));
+    const uint8_t* m = mask + row * width;
+    long long* o = out_idx + row * width;
+    long long offset = 0;
+    int step = 0;
+    for (long long base = 0; base < limit; base += NW * 64, ++step) {
+        const long long j = base + tid;
+        const bool on = j < limit && m[j] != 0;
+        const unsigned long long b = __ballot(on);
+        if (lane == 0) s_cnt[step & 1][wave] = __popcll(b);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int v = s_cnt[step & 1][w];
+            total += v;
+            if (w < wave) before += v;
+        }
+        if (on) o[offset + before + __popcll(b & ((1ull << lane) - 1ull))] = j;
+        offset += total;
+    }
+    for (long long j = offset + tid; j < width; j += NW * 64) o[j] = 0;
+    if (tid == 0) out_sizes[row] = offset;
+}
+
 template <int VB>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const void* __restrict__ flat_, void* __restrict__ dst_,
                                                         const long long* __restrict__ offsets,
@@ -468,9 +505,19 @@ int accv_ragged_mask_to_indices(const void* mask_u8, const void* valid_counts_or
     if (batch == 0) return ACCV_OK;
     if (!out_sizes || (width > 0 && (!mask_u8 || !out_indices)))
         return accv::fail(ACCV_EINVAL, "ragged_mask_to_indices: null pointer");
+    const uint8_t* m = static_cast<const uint8_t*>(mask_u8);
+    if (width > 512 && batch <= 0x7fffffff) {  // wide rows: a workgroup per row (16x / 4x the lanes of a wave per row)
+        if (width > 4096)
+            hipLaunchKernelGGL((mask_to_indices_block_kernel<16>), dim3((unsigned)batch), dim3(1024), 0, stream, m,
+                               valid_counts_or_null, valid_i64, width, out_indices, out_sizes);
+        else
+            hipLaunchKernelGGL((mask_to_indices_block_kernel<4>), dim3((unsigned)batch), dim3(256), 0, stream, m,
+                               valid_counts_or_null, valid_i64, width, out_indices, out_sizes);
+        return accv::check_launch("ragged_mask_to_indices");
+    }
     const unsigned grid = (unsigned)((batch + 3) / 4);
-    hipLaunchKernelGGL(mask_to_indices_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const uint8_t*>(mask_u8),
-                       valid_counts_or_null, valid_i64, batch, width, out_indices, out_sizes);
+    hipLaunchKernelGGL(mask_to_indices_kernel, dim3(grid), dim3(256), 0, stream, m, valid_counts_or_null, valid_i64, batch,
+                       width, out_indices, out_sizes);
     return accv::check_launch("ragged_mask_to_indices");
 }
 

@@ -59,6 +59,29 @@ def main():
             "pack_rows_GBps": bytes_p / t_p / 1e9,
             "us": {"gather": t_g * 1e6, "scatter": t_s * 1e6, "torch_gather": t_tg * 1e6, "torch_scatter": t_ts * 1e6,
                    "pack": t_p * 1e6}})
+    # the remaining kernels at one large shape: pad fill (write-only), mask -> indices (ballot compaction), accumulate
+    from accvlab.batching_helpers import RaggedBatch
+
+    b, n, row = 64, 8192, 256
+    d = row // 4
+    data = torch.randn(b, n, d, device=dev)
+    counts = torch.randint(n // 4, n + 1, (b,), generator=g).to(dev)
+    rb = RaggedBatch(data, sample_sizes=counts)
+    t_pad = timeit(lambda: rb.set_padded_to(0.0))
+    pad_bytes = int((n - counts).sum()) * row
+    mask = (torch.rand(b, n * 8, generator=g) < 0.3).to(dev)
+    t_m2i = timeit(lambda: ext.mask_to_indices(mask))
+    k = 4096
+    idx = torch.randint(0, n, (b, k), generator=g).to(dev)                     # duplicates -> real atomics
+    kc = torch.full((b,), k, device=dev)
+    src = torch.randn(b, k, d, device=dev)
+    t_acc = timeit(lambda: ext.backward_new_tensor(src, idx, kc, n, 0.0, True))
+    acc_bytes = b * k * 2 * row + b * n * row                                 # read rows + atomic RMW + zero-filled result
+    print(json.dumps({"shape": {"batch": b, "rows": n, "row_bytes": row},
+                      "pad_fill_GBps": pad_bytes / t_pad / 1e9, "pad_fill_us": t_pad * 1e6,
+                      "mask_to_indices_GBps_of_mask_plus_index_bytes": (mask.numel() + mask.numel() * 8) / t_m2i / 1e9,
+                      "mask_to_indices_us": t_m2i * 1e6,
+                      "accumulate_scatter_GBps": acc_bytes / t_acc / 1e9, "accumulate_us": t_acc * 1e6}))
     for line in out_lines:
         print(json.dumps(line))
 

@@ -73,3 +73,25 @@ def test_bound_gpu_and_graph_capture():
         torch.cuda.synchronize()
         want = batched_bool_indexing(d2, m2, max_sample_size=12)
         assert torch.equal(out.tensor, want.tensor) and torch.equal(out.sample_sizes, want.sample_sizes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,m", [(5, 64), (3, 513), (7, 900), (2, 4096), (3, 4097), (2, 70001), (1, 1)])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_mask_to_indices_all_kernel_variants(b, m, ragged):
+    # widths <= 512: a wave per row; <= 4096: 4 waves per row; above: 16 waves per row — all order preserving
+    from accvlab.batching_helpers import batched_indexing_access_cuda as ext
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(b * 100003 + m)
+    mask = (torch.rand(b, m, generator=g) < 0.37)
+    valid = torch.randint(0, m + 1, (b,), generator=g) if ragged else None
+    idx, sizes = ext.mask_to_indices(mask.to(dev), valid.to(dev) if ragged else None)
+    idx, sizes = idx.cpu(), sizes.cpu()
+    for i in range(b):
+        row = mask[i].clone()
+        if ragged:
+            row[int(valid[i]):] = False
+        want = torch.nonzero(row).flatten()
+        assert int(sizes[i]) == want.numel()
+        assert torch.equal(idx[i, :want.numel()], want) and bool((idx[i, want.numel():] == 0).all())
