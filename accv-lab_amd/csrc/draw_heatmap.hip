@@ -800,14 +800,18 @@ int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_
 int dispatch_splat(SplatParams p, long long planes, bool clear, bool small_hint, hipStream_t stream)
 {
     const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.hm) & 15u) == 0);
-    // store policy: outputs far larger than L2 + Infinity Cache stream straight to HBM with write-through,
-    // non-temporal stores (measured +2..8 % over write-back, profiles/r01_h1_variants_store_modes*.log); small maps
-    // keep plain stores so that a consumer kernel still finds them in L2.  "hm_nt" overrides (A/B runs).
+    // Store policy and tile height, from in-process A/B runs of the end-of-round kernel on ten boxes
+    // (profiles/r01_h1_ab_rows_store_policy.log): plain stores everywhere (write-through / non-temporal stores, which
+    // paid +2..8 % on the mid-round kernel, now cost 0..7 %), and for fused-clear launches far larger than L2 +
+    // Infinity Cache a 128 x 32 tile (R = 16: -4..-7 % on the slower boxes, +-0.5 % on the fastest); in-place launches
+    // and small maps keep 128 x 16 (more waves, less read-modify-write per touched tile).  "hm_nt" / "hm_rows" override.
     const size_t total_bytes = (size_t)planes * p.H * p.W * sizeof(float);
     const bool plane_fits_rsrc = (size_t)p.H * p.W * sizeof(float) < ((size_t)1 << 31);
     int nt = accv::tune_get("hm_nt", -1);
-    if (nt < 0) nt = (total_bytes > ((size_t)128 << 20) && plane_fits_rsrc) ? 4 : 0;
+    if (nt < 0) nt = 0;
     if (nt >= 2 && !plane_fits_rsrc) nt = 0;
+    int rows = accv::tune_get("hm_rows", -1);
+    if (rows < 0) rows = (clear && total_bytes > ((size_t)128 << 20)) ? 16 : 8;
     // tuning knobs exist for in-process A/B runs (scripts/h1_variants.py); the defaults are the shipped configuration
     if (!p.labels) p.labels = p.radii;  // branch-free candidate loads: always a readable array (ignored when cls < 0)
     if (!vec4) return launch_splat<1, 8>(p, planes, clear, 0, stream);
@@ -815,7 +819,7 @@ int dispatch_splat(SplatParams p, long long planes, bool clear, bool small_hint,
     const int small = accv::tune_get("hm_small", -1);
     if (small > 0 || (small < 0 && small_hint)) return launch_splat_small(p, planes, clear, nt, stream);
     const int wpg = accv::tune_get("hm_wpg", kWavesPerGroup);
-    if (accv::tune_get("hm_rows", 8) == 16) return launch_splat<4, 16>(p, planes, clear, nt, stream);
+    if (rows == 16) return launch_splat<4, 16>(p, planes, clear, nt, stream);
     if (wpg == 4) return launch_splat<4, 8, 4>(p, planes, clear, nt, stream);
     return launch_splat<4, 8>(p, planes, clear, nt, stream);
 }
@@ -958,7 +962,6 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
 
     MultiParams mp{};
     long long tiles = 0;
-    size_t total_bytes = 0;
     int used = 0;
     for (int i = 0; i < num_scales; ++i) {
         if (int rc = check_common(heatmaps[i], heights[i], widths[i], diameter_to_sigma_factor, "draw_heatmap_multiscale"))
@@ -988,7 +991,6 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
         p.grid3d = 0;
         mp.tile_begin[used] = tiles;
         tiles += p.n_tiles;
-        total_bytes += (size_t)batch * p.H * p.W * sizeof(float);
         ++used;
     }
     mp.n_scales = used;
@@ -996,7 +998,7 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
     if (used == 0 || tiles == 0) return ACCV_OK;
     if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: %lld tiles exceed the grid limit", tiles);
     int nt = accv::tune_get("hm_nt", -1);
-    if (nt < 0) nt = total_bytes > ((size_t)128 << 20) ? 4 : 0;   // same store policy as the single-scale path
+    if (nt < 0) nt = 0;   // same store policy as the single-scale path
     const dim3 grid((unsigned)tiles), block(64);
     if (clear) {
         if (nt >= 2)
@@ -1044,7 +1046,6 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
 
     MultiParams mp{};
     long long tiles = 0;
-    size_t total_bytes = 0;
     int used = 0;
     for (int i = 0; i < num_scales; ++i) {
         if (int rc = check_common(heatmaps[i], heights[i], widths[i], diameter_to_sigma_factor, "draw_points_multiscale"))
@@ -1076,7 +1077,6 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
         p.grid3d = 0;
         mp.tile_begin[used] = tiles;
         tiles += p.n_tiles;
-        total_bytes += (size_t)batch * p.H * p.W * sizeof(float);
         ++used;
     }
     mp.n_scales = used;
@@ -1090,7 +1090,7 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
                            reinterpret_cast<const float2*>(points_xy), num_points, n_groups, total_groups,
                            static_cast<float4*>(workspace));
     int nt = accv::tune_get("hm_nt", -1);
-    if (nt < 0) nt = total_bytes > ((size_t)128 << 20) ? 4 : 0;
+    if (nt < 0) nt = 0;
     const dim3 grid((unsigned)tiles), block(64);
     if (clear) {
         if (nt >= 2)

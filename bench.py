@@ -246,7 +246,7 @@ def main():
                    "frames_per_gpu": B, "objects_per_gpu": n_objects, "parallelism": f"frame-sharded x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": "splat_kernel<4, 8, true, 4, 1> (PX=4, R=8, fused clear, sc1+nt stores, 1 wave/WG)", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
+                     "kernel": "splat_kernel<4, 16, true, 0, 1> (PX=4, R=16: 128x32 tile, fused clear, plain stores, 1 wave/WG)", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
         "secondary": extra,
         "device": env or {},
     }

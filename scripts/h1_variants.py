@@ -92,7 +92,7 @@ def main():
                 t = timed(lambda: draw_heatmap_batched(hm, c, r, 6.0, 1.0, clear=(mode == "clear")))
                 res.setdefault(var + (mode,), []).append(t)
         if alt is not None:  # both builds through the bare C-ABI, default knobs
-            for k, v in (("hm_wpg", 1), ("hm_rows", 8), ("hm_nt", -1)):
+            for k, v in (("hm_wpg", 1), ("hm_rows", -1), ("hm_nt", -1)):
                 nat.tune_set(k, v)
             for mode in ("clear", "inplace"):
                 for name, handle in (("shipped", lib), ("alt", alt)):

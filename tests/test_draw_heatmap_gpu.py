@@ -22,8 +22,9 @@ def rb(t, sizes):
     return SimpleNamespace(tensor=t, sample_sizes=sizes)
 
 
-_VARIANTS = {"shipped": {}, "rows16": {"hm_rows": 16}, "wpg4": {"hm_wpg": 4}, "small-splat": {"hm_small": 1}}
-_DEFAULTS = {"hm_rows": 8, "hm_wpg": 1, "hm_small": -1}
+_VARIANTS = {"shipped": {}, "rows16": {"hm_rows": 16}, "rows8-wt-nt": {"hm_rows": 8, "hm_nt": 4}, "wpg4": {"hm_wpg": 4},
+             "small-splat": {"hm_small": 1}}
+_DEFAULTS = {"hm_rows": -1, "hm_nt": -1, "hm_wpg": 1, "hm_small": -1}
 
 
 @pytest.fixture(autouse=True, params=list(_VARIANTS), ids=list(_VARIANTS))
