@@ -233,6 +233,14 @@ __device__ __forceinline__ Hit make_hit(const SplatParams& p, const TileCtx& t, 
     return Hit{x, y, c2, box};
 }
 
+// the same for two candidates at once (v_max3_f32 follows the same NaN rule: NaN operands are skipped)
+__device__ __forceinline__ float max3_skip_nan(float acc, float a, float b)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(a), "v"(b));
+    return r;
+}
+
 template <int PX, int R, bool CLEAR, int SM, int WPG, int SRC>
 __device__ __forceinline__ void splat_body(const SplatParams& p, long long linear_group)
 {
@@ -308,18 +316,40 @@ __device__ __forceinline__ void splat_body(const SplatParams& p, long long linea
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- accumulate: per hit PX column factors in registers, row factors from LDS
+        // ---- accumulate: per hit PX column factors in registers, row factors from LDS.  Hits are taken two at a time:
+        // acc = max3(acc, ex_a * ey_a, ex_b * ey_b) is 3 VALU ops per pixel for two hits instead of 4
         const unsigned colr0 = (unsigned)(lane & 31) * PX;  // first column of this lane, tile relative
-        for (int h = 0; h < nh; ++h) {
-            const Hit hx = s_hit[wave][h];
+        auto column_factors = [&](const Hit& hx, float (&ex)[PX]) {
             const unsigned xlo = hx.box & 255u, xhi = (hx.box >> 8) & 255u;
-            float ex[PX];
 #pragma unroll
             for (int c = 0; c < PX; ++c) {
                 const float d = (float)(col0 + c - hx.x);
                 const float e = raw_exp2(-(d * d) * hx.c2);
                 ex[c] = (colr0 + c >= xlo && colr0 + c < xhi) ? e : __builtin_nanf("");
             }
+        };
+        int h = 0;
+        // (fused-clear instantiations only: the in-place ones are register bound, and the second set of factors costs
+        // them a wave of occupancy — sparse in-place launches lost 5 %)
+        for (; CLEAR && h + 1 < nh; h += 2) {
+            float exa[PX], exb[PX];
+            column_factors(s_hit[wave][h], exa);
+            column_factors(s_hit[wave][h + 1], exb);
+#pragma unroll
+            for (int q = 0; q < R / 4; ++q) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&s_ey[wave][h][sub * R + 4 * q]);
+                const float4 b4 = *reinterpret_cast<const float4*>(&s_ey[wave][h + 1][sub * R + 4 * q]);
+                const float eya[4] = {a4.x, a4.y, a4.z, a4.w}, eyb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < PX; ++c)
+                        acc[4 * q + i][c] = max3_skip_nan(acc[4 * q + i][c], exa[c] * eya[i], exb[c] * eyb[i]);
+            }
+        }
+        for (; h < nh; ++h) {
+            float ex[PX];
+            column_factors(s_hit[wave][h], ex);
 #pragma unroll
             for (int q = 0; q < R / 4; ++q) {
                 const float4 e4 = *reinterpret_cast<const float4*>(&s_ey[wave][h][sub * R + 4 * q]);
