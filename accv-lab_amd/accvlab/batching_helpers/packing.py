@@ -155,6 +155,8 @@ def _fast_pack(data_list, device):
     """combine_data (flatten mode) through the C++ loops of _bh_host; None = not a plain case, use the python path.
     Returns (padded on the target device, int64 sizes on the target device)."""
     target = None if device is None else torch.device(device)
+    if target is not None and target.type == "cuda" and target.index is None:
+        target = torch.device("cuda", torch.cuda.current_device())   # "cuda" == the current device
     if target is None or target.type == "cpu":
         fast = _bh.pack_cpu(data_list, False)     # declines unless every sample is a plain CPU tensor
         if fast is not None:
