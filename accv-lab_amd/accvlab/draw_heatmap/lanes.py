@@ -10,6 +10,7 @@ reference operators that exist: sample every lane at ``num_samples`` arc-length-
 """
 from __future__ import annotations
 
+import ctypes
 from types import SimpleNamespace
 from typing import Optional
 
@@ -160,8 +161,6 @@ def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: in
         sizes = num_lanes.clamp(0, l) * num_samples
         if sizes.dtype not in (torch.int32, torch.int64):
             sizes = sizes.to(torch.int64)
-    import ctypes
-
     lib = _nat.lib()
     k = len(heatmaps)
     ptrs = (ctypes.c_void_p * k)(*[hm.data_ptr() for hm in heatmaps])

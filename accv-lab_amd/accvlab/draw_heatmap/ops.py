@@ -8,6 +8,7 @@ the heat-map's device; nothing synchronises.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional
 
 import torch
@@ -284,8 +285,6 @@ def draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diamete
             ci, ri = get_centers_and_radii(centers, bboxes, f)
             draw_heatmap_batched(hm, ci, ri, diameter_to_sigma_factor, k_scale, clear=clear)
         return
-    import ctypes
-
     n = len(heatmaps)
     ptrs = (ctypes.c_void_p * n)(*[hm.data_ptr() for hm in heatmaps])
     hs = (ctypes.c_int * n)(*[hm.size(1) for hm in heatmaps])
