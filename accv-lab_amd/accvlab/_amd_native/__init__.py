@@ -17,6 +17,7 @@ OK = 0
 HM_CLEAR = 1
 HM_COUNTS_I64 = 2
 HM_SMALL_RADII = 4
+HM_WRITE_THROUGH = 8
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

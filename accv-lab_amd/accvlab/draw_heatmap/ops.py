@@ -51,6 +51,7 @@ def draw_heatmap(
     *,
     clear: bool = False,
     small_radii: bool = False,
+    write_through: bool = False,
 ) -> None:
     """Draw N Gaussians into ``heatmaps[P,H,W]`` (fp32, in place, element-wise max).
 
@@ -64,6 +65,8 @@ def draw_heatmap(
         clear: (extension) overwrite the map with max(0, splats) instead of max-ing into its content.
         small_radii: (extension) performance hint — the radii are a few pixels (key points, lane samples; boxes up to
             ~15x15): use the kernel that walks each object's box instead of updating whole tiles.  Same results.
+        write_through: (extension) performance hint — write-through non-temporal stores; pays a few per cent for dense
+            launches that rewrite hundreds of MB, costs up to 27 % for sparse in-place ones (default off).  Same results.
 
     Reference: draw_heatmap.cpp:132-134 -> draw_heatmap_launcher (draw_heatmap_cuda.cu:62-89).
     """
@@ -96,7 +99,8 @@ def draw_heatmap(
         status = lib.accv_draw_heatmap_flat_f32(
             heatmaps.data_ptr(), planes, height, width, centers.data_ptr(), radii.data_ptr(),
             heatmap_idxes.data_ptr(), n, float(diameter_to_sigma_factor), float(k_scale),
-            (_nat.HM_CLEAR if clear else 0) | (_nat.HM_SMALL_RADII if small_radii else 0), ws.data_ptr(), ws_bytes,
+            (_nat.HM_CLEAR if clear else 0) | (_nat.HM_SMALL_RADII if small_radii else 0) |
+            (_nat.HM_WRITE_THROUGH if write_through else 0), ws.data_ptr(), ws_bytes,
             _nat.stream_ptr(heatmaps.device))
         # the workspace is only used by kernels already enqueued on the current stream; the caching
         # allocator re-issues it stream-ordered, so dropping the reference here is safe
@@ -113,6 +117,7 @@ def draw_heatmap_batched(
     *,
     clear: bool = False,
     small_radii: bool = False,
+    write_through: bool = False,
 ) -> None:
     """Draw a ragged batch of Gaussians (in place, element-wise max).
 
@@ -125,6 +130,7 @@ def draw_heatmap_batched(
         labels: optional RaggedBatch int32 ``[B, Nmax]`` of class indices -> one plane per class.
         clear: (extension) fused zero-fill + draw in one write-only pass.
         small_radii: (extension) performance hint for point-like objects, see :func:`draw_heatmap`.
+        write_through: (extension) store-policy hint for dense launches over huge maps, see :func:`draw_heatmap`.
 
     Only ``centers.sample_sizes`` decides how many leading objects of a sample are drawn; padded slots are
     never touched.  Reference: funtions/draw_heatmap_batched.py:27-84 -> draw_heatmap_batched_launcher /
@@ -191,7 +197,7 @@ def draw_heatmap_batched(
         return
 
     flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0) | \
-        (_nat.HM_SMALL_RADII if small_radii else 0)
+        (_nat.HM_SMALL_RADII if small_radii else 0) | (_nat.HM_WRITE_THROUGH if write_through else 0)
     with _nat.device_guard(heatmap.device):
         status = _nat.lib().accv_draw_heatmap_batched_f32(
             heatmap.data_ptr(), batch, num_classes, height, width, centers_t.data_ptr(), radii_t.data_ptr(),

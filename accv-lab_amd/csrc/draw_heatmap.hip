@@ -827,8 +827,9 @@ int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_
     return accv::check_launch("draw_heatmap splat kernel");
 }
 
-int dispatch_splat(SplatParams p, long long planes, bool clear, bool small_hint, hipStream_t stream)
+int dispatch_splat(SplatParams p, long long planes, bool clear, unsigned flags, hipStream_t stream)
 {
+    const bool small_hint = (flags & ACCV_HM_SMALL_RADII) != 0;
     const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.hm) & 15u) == 0);
     // Store policy and tile height, from in-process A/B runs of the end-of-round kernel on ten boxes
     // (profiles/r01_h1_ab_rows_store_policy.log): plain stores everywhere (write-through / non-temporal stores, which
@@ -838,7 +839,7 @@ int dispatch_splat(SplatParams p, long long planes, bool clear, bool small_hint,
     const size_t total_bytes = (size_t)planes * p.H * p.W * sizeof(float);
     const bool plane_fits_rsrc = (size_t)p.H * p.W * sizeof(float) < ((size_t)1 << 31);
     int nt = accv::tune_get("hm_nt", -1);
-    if (nt < 0) nt = 0;
+    if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;
     if (nt >= 2 && !plane_fits_rsrc) nt = 0;
     int rows = accv::tune_get("hm_rows", -1);
     if (rows < 0) rows = (clear && total_bytes > ((size_t)128 << 20)) ? 16 : 8;
@@ -928,7 +929,7 @@ int accv_draw_heatmap_flat_f32(float* heatmaps, int num_planes, int height, int 
     p.W = width;
     p.factor = diameter_to_sigma_factor;
     p.k = k_scale;
-    return dispatch_splat(p, num_planes, clear, (flags & ACCV_HM_SMALL_RADII) != 0, stream);
+    return dispatch_splat(p, num_planes, clear, flags, stream);
 }
 
 int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, int height, int width,
@@ -966,7 +967,7 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
     p.k = k_scale;
     p.counts_i64 = (flags & ACCV_HM_COUNTS_I64) ? 1 : 0;
     const long long planes = (long long)batch * (num_classes > 0 ? num_classes : 1);
-    return dispatch_splat(p, planes, clear, (flags & ACCV_HM_SMALL_RADII) != 0, stream);
+    return dispatch_splat(p, planes, clear, flags, stream);
 }
 
 int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights, const int* widths, const float* strides,

@@ -34,6 +34,10 @@ extern "C" {
 #define ACCV_HM_SMALL_RADII 4u /* hint: radii of a few pixels (lane samples, key points; boxes up to ~15x15): take the
                                  kernel that walks each object's box instead of updating whole tiles.  Results do
                                  not depend on the hint; objects of any size stay correct, only slower. */
+#define ACCV_HM_WRITE_THROUGH 8u /* hint: write the map with write-through non-temporal stores (sc1 nt) instead of plain
+                                    ones.  Pays 1-7 % for launches that rewrite far more than L2 + Infinity Cache hold AND
+                                    are compute heavy (dense batches, in-place over most of the frame); costs up to 27 %
+                                    for sparse in-place launches, which is why it is not the default.  Same results. */
 
 const char* accv_last_error(void);
 int accv_version(void);

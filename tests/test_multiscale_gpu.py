@@ -122,3 +122,36 @@ def test_extension_module_entry_points_match_the_public_operators():
     ext.draw_heatmap_batched_classwise_impl(a, centers, radii, counts, labels, 6.0, 0.7)
     draw_heatmap_batched(ref, rb(centers), rb(radii), 6.0, 0.7, rb(labels))
     assert torch.equal(a, ref) and float(a.max()) > 0
+
+
+@pytest.mark.parametrize("clear", [True, False])
+def test_store_policy_hints_do_not_change_results(clear):
+    # write_through (ACCV_HM_WRITE_THROUGH) and small_radii (ACCV_HM_SMALL_RADII) select other kernels / store
+    # instructions, never other values
+    from types import SimpleNamespace
+
+    from accvlab.draw_heatmap import draw_heatmap, draw_heatmap_batched
+
+    g = torch.Generator().manual_seed(4)
+    b, n, h, w = 4, 11, 70, 132
+    centers = torch.stack([torch.randint(-3, w + 3, (b, n), generator=g), torch.randint(-3, h + 3, (b, n), generator=g)], -1)
+    centers = centers.to(torch.int32).to(DEV)
+    radii = torch.randint(0, 30, (b, n), generator=g).to(torch.int32).to(DEV)
+    counts = torch.tensor([11, 0, 5, 9], device=DEV)
+    rb = lambda t: SimpleNamespace(tensor=t, sample_sizes=counts)  # noqa: E731
+    base = torch.rand(b, h, w, generator=g).mul_(0.2).to(DEV)
+    ref = base.clone()
+    draw_heatmap_batched(ref, rb(centers), rb(radii), clear=clear)
+    for kw in ({"write_through": True}, {"small_radii": True}, {"write_through": True, "small_radii": True}):
+        got = base.clone()
+        draw_heatmap_batched(got, rb(centers), rb(radii), clear=clear, **kw)
+        if kw.get("small_radii"):
+            assert float((got - ref).abs().max()) <= 1e-6       # exp of the sum vs product of two exps
+        else:
+            assert torch.equal(got, ref)
+    idx = torch.arange(b, dtype=torch.int32, device=DEV).repeat_interleave(n)
+    flat_ref, flat_wt = base.clone(), base.clone()
+    draw_heatmap(flat_ref, centers.reshape(-1, 2).contiguous(), radii.reshape(-1).contiguous(), idx, clear=clear)
+    draw_heatmap(flat_wt, centers.reshape(-1, 2).contiguous(), radii.reshape(-1).contiguous(), idx, clear=clear,
+                 write_through=True)
+    assert torch.equal(flat_ref, flat_wt)
