@@ -419,8 +419,9 @@ __global__ __launch_bounds__(64) void splat_multi_kernel(const MultiParams mp)
 // boxes of a few pixels (a lane sample of radius 2 covers 5x5) that is 2048 pixel updates for 25 useful ones, and
 // tiles that a lane crosses hold 10^2 such hits.  This variant keeps the tile in LDS instead (8 KB per wave) and, per
 // hit, lets 16 lanes walk the pixels of the hit's clipped box only: v = k * exp2(-(dx^2 + dy^2) c), one LDS float-max
-// atomic (ds_max_f32) per box pixel, four hits in flight per wave.  Correct for any radius, but only faster below ~15x15 boxes; the host selects it on the
-// caller's ACCV_HM_SMALL_RADII hint.  Same culling, same store path, same clear / in-place semantics.
+// atomic (ds_max_f32) per box pixel, four hits in flight per wave.  Correct for any radius, but only faster below
+// ~15x15 boxes; the host selects it on the caller's ACCV_HM_SMALL_RADII hint.  Same culling, same store path, same
+// clear / in-place semantics.  SRC = 2 (splat_points_multi_kernel) reads float sample points and culls in two levels.
 template <bool CLEAR, int SM, int SRC>
 __device__ __forceinline__ void small_body(const SplatParams& p, long long linear_group)
 {
