@@ -18,6 +18,7 @@ HM_CLEAR = 1
 HM_COUNTS_I64 = 2
 HM_SMALL_RADII = 4
 HM_WRITE_THROUGH = 8
+HM_GROUP_BOXES_GIVEN = 16
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -65,6 +66,7 @@ SIGNATURES = {
     # lane_helpers
     "accv_polyline_scratch_bytes": (_sz, [_ll, _i, _i]),
     "accv_polyline_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "accv_polyline_sample_boxes": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 # not in the public header (bench / profiling knobs)
 _PRIVATE = {

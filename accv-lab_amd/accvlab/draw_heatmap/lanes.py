@@ -96,9 +96,11 @@ def draw_polylines_batched(heatmap: torch.Tensor, polylines: torch.Tensor, num_s
                          clear=clear, small_radii=radius <= 7)
 
 
-def sample_lanes(polylines: torch.Tensor, num_samples: int, *, num_points: Optional[torch.Tensor] = None) -> torch.Tensor:
+def sample_lanes(polylines: torch.Tensor, num_samples: int, *, num_points: Optional[torch.Tensor] = None,
+                 group_boxes_ptr: int = 0) -> torch.Tensor:
     """Arc-length-uniform samples of ``polylines`` f32 ``[B, L, P, 2]`` -> f32 ``[B, L * num_samples, 2]`` (source
-    pixels; samples of empty lanes are NaN).  One launch of the polyline sampler."""
+    pixels; samples of empty lanes are NaN).  One launch of the polyline sampler; with ``group_boxes_ptr`` (and
+    ``num_samples % 64 == 0``) the same launch also writes the bounding box of every 64 consecutive samples there."""
     if not (isinstance(polylines, torch.Tensor) and polylines.is_cuda):
         raise RuntimeError("polylines must be a CUDA tensor")
     if not (polylines.dim() == 4 and polylines.size(3) == 2):
@@ -120,7 +122,8 @@ def sample_lanes(polylines: torch.Tensor, num_samples: int, *, num_points: Optio
     frac = _cached(("frac", b * l, num_samples, dev), lambda: torch.linspace(
         0.0, 1.0, num_samples, device=dev).unsqueeze(0).expand(b * l, num_samples).contiguous()
         if num_samples > 1 else torch.zeros((b * l, 1), device=dev))
-    samples = _poly._gpu(polylines.contiguous().view(b * l, p, 2), frac, counts, None, True, True, False)[0]
+    samples = _poly._gpu(polylines.contiguous().view(b * l, p, 2), frac, counts, None, True, True, False,
+                         group_boxes_ptr)[0]
     return samples.view(b, l * num_samples, 2)
 
 
@@ -150,9 +153,16 @@ def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: in
             draw_polylines_batched(hm, polylines, num_samples, radius, f, diameter_to_sigma_factor, k_scale,
                                    num_points=num_points, num_lanes=num_lanes, clear=clear)
         return
-    samples = sample_lanes(polylines, num_samples, num_points=num_points)
     n = l * num_samples
     dev = polylines.device
+    lib = _nat.lib()
+    with _nat.device_guard(dev):
+        nbytes = lib.accv_draw_points_workspace_bytes(b, n)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    # the sampler writes the group boxes itself when the groups of 64 do not straddle lanes (one launch less)
+    boxes_by_sampler = num_samples % 64 == 0 and b * l > 0
+    samples = sample_lanes(polylines, num_samples, num_points=num_points,
+                           group_boxes_ptr=work.data_ptr() if boxes_by_sampler else 0)
     if num_lanes is None:
         sizes = _cached(("full", b, n, dev), lambda: torch.full((b,), n, dtype=torch.int32, device=dev))
     else:
@@ -161,16 +171,14 @@ def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: in
         sizes = num_lanes.clamp(0, l) * num_samples
         if sizes.dtype not in (torch.int32, torch.int64):
             sizes = sizes.to(torch.int64)
-    lib = _nat.lib()
     k = len(heatmaps)
     ptrs = (ctypes.c_void_p * k)(*[hm.data_ptr() for hm in heatmaps])
     hs = (ctypes.c_int * k)(*[hm.size(1) for hm in heatmaps])
     ws_ = (ctypes.c_int * k)(*[hm.size(2) for hm in heatmaps])
     st = (ctypes.c_float * k)(*strides)
-    flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if sizes.dtype == torch.int64 else 0)
+    flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if sizes.dtype == torch.int64 else 0) | \
+        (_nat.HM_GROUP_BOXES_GIVEN if boxes_by_sampler else 0)
     with _nat.device_guard(dev):
-        nbytes = lib.accv_draw_points_workspace_bytes(b, n)
-        work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         status = lib.accv_draw_points_multiscale_f32(
             ptrs, hs, ws_, st, k, b, samples.data_ptr(), sizes.data_ptr(), n, int(radius),
             float(diameter_to_sigma_factor), float(k_scale), flags, work.data_ptr(), nbytes, _nat.stream_ptr(dev))

@@ -55,7 +55,9 @@ def _check_size_values(checks):
             raise RuntimeError(f"{name} values must be in [0, {limit}]")
 
 
-def _gpu(points, distances, p_sizes, d_sizes, relative, want_points, want_lengths):
+def _gpu(points, distances, p_sizes, d_sizes, relative, want_points, want_lengths, group_boxes_ptr=0):
+    """``group_boxes_ptr``: device pointer for the bounding boxes of every 64 consecutive samples (f32, 2-D points only;
+    accv_polyline_sample_boxes) or 0."""
     lib = _nat.lib()
     b, pmax, dims = points.shape
     qmax = distances.shape[1] if distances is not None else 0
@@ -75,12 +77,12 @@ def _gpu(points, distances, p_sizes, d_sizes, relative, want_points, want_length
     with _nat.device_guard(points.device):
         sb = lib.accv_polyline_scratch_bytes(b, pmax, code)
         scratch = torch.empty(sb, dtype=torch.uint8, device=points.device) if sb else None
-        _nat.check(lib.accv_polyline_sample(
+        _nat.check(lib.accv_polyline_sample_boxes(
             points.data_ptr(), distances.data_ptr() if distances is not None else None,
             p_sizes.data_ptr() if p_sizes is not None else None, d_sizes.data_ptr() if d_sizes is not None else None,
-            out_p.data_ptr() if out_p is not None else None, out_l.data_ptr() if out_l is not None else None, b, pmax,
-            qmax, dims, code, c64, int(bool(relative)), scratch.data_ptr() if scratch is not None else None, sb,
-            _nat.stream_ptr(points.device)), "polyline")
+            out_p.data_ptr() if out_p is not None else None, out_l.data_ptr() if out_l is not None else None,
+            group_boxes_ptr or None, b, pmax, qmax, dims, code, c64, int(bool(relative)),
+            scratch.data_ptr() if scratch is not None else None, sb, _nat.stream_ptr(points.device)), "polyline")
     return out_p, out_l
 
 

@@ -1117,7 +1117,7 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
     if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: %lld tiles exceed the grid limit", tiles);
     const long long total_groups = (long long)batch * n_groups;
     if (total_groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: too many point groups");
-    if (total_groups > 0)
+    if (total_groups > 0 && !(flags & ACCV_HM_GROUP_BOXES_GIVEN))
         hipLaunchKernelGGL(group_boxes_kernel, dim3((unsigned)total_groups), dim3(64), 0, stream,
                            reinterpret_cast<const float2*>(points_xy), num_points, n_groups, total_groups,
                            static_cast<float4*>(workspace));

@@ -80,6 +80,7 @@ struct PolyParams {
     void* out_points;       // [B, Q, D] or null
     void* out_lengths;      // [B] or null
     void* scratch;          // [B, P] accumulation-type elements, used when P does not fit LDS
+    float* out_boxes;       // optional (f32, D == 2): [B, ceil(Q/64), 4] bounding box of every 64 consecutive samples
     long long batch;
     int P, Q, D;
     int counts_i64, relative, use_scratch;
@@ -112,6 +113,12 @@ __global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
         if (out)
             for (int i = t; i < q * p.D; i += kThreads) S::store(out + i, nan);
         if (p.out_lengths && t == 0) S::store(static_cast<T*>(p.out_lengths) + b, nan);
+        if (p.out_boxes) {
+            const int groups = (p.Q + 63) / 64;
+            const float inf = __builtin_inff();
+            for (int g = t; g < groups; g += kThreads)
+                reinterpret_cast<float4*>(p.out_boxes)[b * groups + g] = make_float4(inf, inf, -inf, -inf);
+        }
         return;
     }
 
@@ -164,41 +171,66 @@ __global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
     // ---- queries
     const T* dist = static_cast<const T*>(p.distances) + (size_t)b * p.Q;
     const Acc eps = std::numeric_limits<Acc>::epsilon();
-    for (int i = t; i < q; i += kThreads) {
-        Acc d = S::load(dist + i);
-        if (p.relative) d *= total;
-        T* res = out + (size_t)i * p.D;
-        // last index whose accumulated distance is <= d (polyline_common.cuh:89-116)
-        int idx;
-        if (accum[0] > d) {
-            idx = -1;
-        } else if (accum[n - 1] < d) {
-            idx = n - 1;
-        } else {
-            int mn = 0, mx = n - 1;
-            while (mx - mn > 1) {
-                const int c = (mx + mn) >> 1;
-                const Acc v = accum[c];
-                if (v < d) mn = c;
-                else if (v > d) mx = c;
-                else mn = mx = c;
-            }
-            idx = mn;
-        }
-        if (idx >= 0 && idx < n - 1) {
-            const Acc d0 = accum[idx], d1 = accum[idx + 1], len = d1 - d0;
-            const T* a = pts + (size_t)idx * p.D;
-            const T* c = a + p.D;
-            if (len >= eps) {
-                const Acc w1 = (d - d0) / len, w0 = (d1 - d) / len;
-                for (int k = 0; k < p.D; ++k) S::store(res + k, S::load(a + k) * w0 + S::load(c + k) * w1);
+    // (whole waves walk the loop together: when group boxes are wanted, the 64 lanes of a wave hold 64 consecutive samples
+    // and reduce their bounding box with shuffles)
+    const int q_span = p.out_boxes ? ((p.Q + kThreads - 1) / kThreads) * kThreads : q;
+    const int groups = (p.Q + 63) / 64;
+    for (int i = t; i < q_span; i += kThreads) {
+        float bx = __builtin_nanf(""), by = bx;  // sample coordinates for the group box (D == 2, f32 instantiation)
+        if (i < q) {
+            Acc d = S::load(dist + i);
+            if (p.relative) d *= total;
+            T* res = out + (size_t)i * p.D;
+            // last index whose accumulated distance is <= d (polyline_common.cuh:89-116)
+            int idx;
+            if (accum[0] > d) {
+                idx = -1;
+            } else if (accum[n - 1] < d) {
+                idx = n - 1;
             } else {
-                for (int k = 0; k < p.D; ++k) S::copy(res + k, a + k);
+                int mn = 0, mx = n - 1;
+                while (mx - mn > 1) {
+                    const int c = (mx + mn) >> 1;
+                    const Acc v = accum[c];
+                    if (v < d) mn = c;
+                    else if (v > d) mx = c;
+                    else mn = mx = c;
+                }
+                idx = mn;
             }
-        } else if (idx == -1) {
-            for (int k = 0; k < p.D; ++k) S::copy(res + k, pts + k);
-        } else {
-            for (int k = 0; k < p.D; ++k) S::copy(res + k, pts + (size_t)(n - 1) * p.D + k);
+            if (idx >= 0 && idx < n - 1) {
+                const Acc d0 = accum[idx], d1 = accum[idx + 1], len = d1 - d0;
+                const T* a = pts + (size_t)idx * p.D;
+                const T* c = a + p.D;
+                if (len >= eps) {
+                    const Acc w1 = (d - d0) / len, w0 = (d1 - d) / len;
+                    for (int k = 0; k < p.D; ++k) S::store(res + k, S::load(a + k) * w0 + S::load(c + k) * w1);
+                } else {
+                    for (int k = 0; k < p.D; ++k) S::copy(res + k, a + k);
+                }
+            } else if (idx == -1) {
+                for (int k = 0; k < p.D; ++k) S::copy(res + k, pts + k);
+            } else {
+                for (int k = 0; k < p.D; ++k) S::copy(res + k, pts + (size_t)(n - 1) * p.D + k);
+            }
+            if (p.out_boxes) {  // what this thread just wrote
+                bx = (float)S::load(res);
+                by = (float)S::load(res + 1);
+            }
+        }
+        if (p.out_boxes) {
+            const float inf = __builtin_inff();
+            const bool ok = bx == bx && by == by;
+            float x0 = ok ? bx : inf, y0 = ok ? by : inf, x1 = ok ? bx : -inf, y1 = ok ? by : -inf;
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                x0 = fminf(x0, __shfl_xor(x0, sft));
+                y0 = fminf(y0, __shfl_xor(y0, sft));
+                x1 = fmaxf(x1, __shfl_xor(x1, sft));
+                y1 = fmaxf(y1, __shfl_xor(y1, sft));
+            }
+            const int g = i >> 6;
+            if ((t & 63) == 0 && g < groups) reinterpret_cast<float4*>(p.out_boxes)[b * groups + g] = make_float4(x0, y0, x1, y1);
         }
     }
 }
@@ -216,12 +248,16 @@ size_t accv_polyline_scratch_bytes(long long batch, int max_points, int dtype)
     return need <= (size_t)kLdsBudgetBytes ? 0 : need * (size_t)batch;
 }
 
-int accv_polyline_sample(const void* points, const void* distances, const void* point_counts, const void* dist_counts,
-                         void* out_points, void* out_lengths, long long batch, int max_points, int max_distances,
-                         int num_dims, int dtype, int counts_i64, int relative, void* scratch, size_t scratch_bytes,
-                         void* stream_)
+int accv_polyline_sample_boxes(const void* points, const void* distances, const void* point_counts, const void* dist_counts,
+                               void* out_points, void* out_lengths, float* out_group_boxes, long long batch, int max_points,
+                               int max_distances, int num_dims, int dtype, int counts_i64, int relative, void* scratch,
+                               size_t scratch_bytes, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (out_group_boxes && (dtype != kPF32 || num_dims != 2 || !out_points))
+        return accv::fail(ACCV_EINVAL, "polyline: group boxes need float32 samples of 2-D points");
+    if (out_group_boxes && (reinterpret_cast<uintptr_t>(out_group_boxes) & 15u))
+        return accv::fail(ACCV_EINVAL, "polyline: group boxes need 16-byte alignment");
     if (batch < 0 || max_points < 0 || max_distances < 0 || num_dims < 0)
         return accv::fail(ACCV_EINVAL, "polyline: negative extent");
     if (dtype < kPF32 || dtype > kPBF16) return accv::fail(ACCV_EINVAL, "polyline: unsupported dtype code %d", dtype);
@@ -237,6 +273,7 @@ int accv_polyline_sample(const void* points, const void* distances, const void* 
     p.dist_counts = dist_counts;
     p.out_points = (max_distances > 0 && num_dims > 0) ? out_points : nullptr;
     p.out_lengths = out_lengths;
+    p.out_boxes = out_group_boxes;
     p.batch = batch;
     p.P = max_points;
     p.Q = max_distances;
@@ -261,5 +298,15 @@ int accv_polyline_sample(const void* points, const void* distances, const void* 
         default: hipLaunchKernelGGL((polyline_kernel<kPBF16>), grid, block, lds, stream, p); break;
     }
     return accv::check_launch("polyline");
+}
+
+int accv_polyline_sample(const void* points, const void* distances, const void* point_counts, const void* dist_counts,
+                         void* out_points, void* out_lengths, long long batch, int max_points, int max_distances,
+                         int num_dims, int dtype, int counts_i64, int relative, void* scratch, size_t scratch_bytes,
+                         void* stream)
+{
+    return accv_polyline_sample_boxes(points, distances, point_counts, dist_counts, out_points, out_lengths, nullptr, batch,
+                                      max_points, max_distances, num_dims, dtype, counts_i64, relative, scratch,
+                                      scratch_bytes, stream);
 }
 }

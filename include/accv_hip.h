@@ -38,6 +38,8 @@ extern "C" {
                                     ones.  Pays 1-7 % for launches that rewrite far more than L2 + Infinity Cache hold AND
                                     are compute heavy (dense batches, in-place over most of the frame); costs up to 27 %
                                     for sparse in-place launches, which is why it is not the default.  Same results. */
+#define ACCV_HM_GROUP_BOXES_GIVEN 16u /* accv_draw_points_multiscale_f32 only: `workspace` already holds the group boxes
+                                         (written by accv_polyline_sample_boxes); skip the box launch */
 
 const char* accv_last_error(void);
 int accv_version(void);
@@ -239,6 +241,15 @@ int accv_polyline_sample(const void* points, const void* distances, const void* 
                          void* out_points, void* out_lengths, long long batch, int max_points, int max_distances,
                          int num_dims, int dtype, int counts_i64, int relative, void* scratch, size_t scratch_bytes,
                          void* stream);
+
+/* The same sampler with one more output (float32 samples of 2-D points only): out_group_boxes f32[batch, ceil(Q/64), 4] =
+ * (xmin, ymin, xmax, ymax) of every 64 consecutive samples of a polyline, NaN samples ignored, (+inf, +inf, -inf, -inf) for
+ * a group without valid samples — what accv_draw_points_multiscale_f32 culls by (ACCV_HM_GROUP_BOXES_GIVEN saves its own
+ * box launch).  NULL = plain accv_polyline_sample. */
+int accv_polyline_sample_boxes(const void* points, const void* distances, const void* point_counts, const void* dist_counts,
+                               void* out_points, void* out_lengths, float* out_group_boxes, long long batch, int max_points,
+                               int max_distances, int num_dims, int dtype, int counts_i64, int relative, void* scratch,
+                               size_t scratch_bytes, void* stream);
 
 /* Streaming fill used by bench.py as the measured write-bandwidth ceiling (not part of the reference API). */
 int accv_fill_f32(float* dst, size_t count, float value, void* stream);

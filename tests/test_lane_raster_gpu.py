@@ -147,3 +147,32 @@ def test_multiscale_lane_raster_fallback_and_large_radius():
     ref = torch.zeros(2, 76, 100, device=dev)
     draw_polylines_batched(ref, pts_d, 40, 12, 4.0, clear=True)
     assert float((a[0] - ref).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("q", [64, 192])
+def test_sampler_group_boxes_match_the_samples(q):
+    # accv_polyline_sample_boxes: bounding box of every 64 consecutive samples, NaN samples ignored, empty groups inverted
+    from accvlab.draw_heatmap import sample_lanes
+
+    dev = torch.device("cuda", 0)
+    b, l, p = 3, 4, 10
+    pts, npts, _ = _lanes(b, l, p, 800.0, 600.0, seed=q, ragged=True)
+    npts[0, 1] = 0                                                   # one empty lane -> NaN samples -> empty groups
+    pts_d, npts_d = torch.from_numpy(pts).to(dev), torch.from_numpy(npts).to(dev)
+    groups = b * l * q // 64
+    boxes = torch.full((groups, 4), 7.0, device=dev)
+    samples = sample_lanes(pts_d, q, num_points=npts_d, group_boxes_ptr=boxes.data_ptr())
+    torch.cuda.synchronize()
+    ref = sample_lanes(pts_d, q, num_points=npts_d)
+    assert torch.equal(torch.nan_to_num(samples, nan=-1.0), torch.nan_to_num(ref, nan=-1.0))
+    s = samples.view(groups, 64, 2).cpu()
+    got = boxes.cpu()
+    inf = float("inf")
+    for g in range(groups):
+        ok = ~torch.isnan(s[g]).any(-1)
+        if ok.any():
+            v = s[g][ok]
+            want = torch.tensor([v[:, 0].min(), v[:, 1].min(), v[:, 0].max(), v[:, 1].max()])
+        else:
+            want = torch.tensor([inf, inf, -inf, -inf])
+        assert torch.equal(got[g], want), (g, got[g], want)
