@@ -175,3 +175,113 @@ def test_named_tuple_compaction():
     mask, datas, sizes, exps = lit.compaction_literal()
     out = get_compact_from_named_tuple(torch.from_numpy(mask), T(torch.from_numpy(datas[0]), 3, torch.from_numpy(datas[1])))
     assert isinstance(out, T) and out.n == 3 and np.array_equal(out.b.tensor.numpy(), exps[1])
+
+
+# ----------------------------------------------------------------------------- round 2: the remaining reference literals
+@pytest.mark.parametrize("fill", [0.0, 1.0, 2.3])
+def test_oracle_inverse_literal(fill):
+    data, idx, counts, n_targets, exp, grad = lit.inverse_literal(fill)
+    out = oracle.scatter_new(data.reshape(6, 4), idx.reshape(6, 4), counts.reshape(6), n_targets, fill, False)
+    assert np.array_equal(out.reshape(2, 3, 5), exp)
+    # backward = gather of the incoming gradient with 0 filler (batched_indexing_ops.py:72-117)
+    g = oracle.gather(np.cos(exp.astype(np.float64)).reshape(6, 5), idx.reshape(6, 4), counts.reshape(6), 0.0)
+    assert np.allclose(g.reshape(2, 3, 4), grad, atol=1e-6)
+
+
+def test_oracle_write_literal():
+    data, idx, counts, into, exp, g_src, g_into = lit.write_literal()
+    out = oracle.scatter_insert(data.reshape(6, 4), idx.reshape(6, 4), counts.reshape(6), into.reshape(6, 5))
+    assert np.array_equal(out.reshape(2, 3, 5), exp)
+    up = np.cos(exp.astype(np.float64)).reshape(6, 5)
+    assert np.allclose(oracle.gather(up, idx.reshape(6, 4), counts.reshape(6), 0.0).reshape(2, 3, 4), g_src, atol=1e-6)
+    assert np.allclose(oracle.insert_const(0.0, idx.reshape(6, 4), counts.reshape(6), up).reshape(2, 3, 5), g_into, atol=1e-6)
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_oracle_bool_index_and_write_literals(multi):
+    data, sizes, mask, exp, out_sizes = (lit.bool_index_multi_literal if multi else lit.bool_index_simple_literal)()
+    b = int(np.prod(sizes.shape))
+    flat = lambda a, w: a.reshape((b, w) + a.shape[sizes.ndim + 1:])  # noqa: E731
+    out, s = oracle.bool_compact(flat(data, data.shape[sizes.ndim]), mask.reshape(b, -1), sizes.reshape(b))
+    assert np.array_equal(s, out_sizes.reshape(b)) and np.array_equal(out, flat(exp, exp.shape[sizes.ndim]))
+    compact, csz, mask, sizes, into, want = lit.bool_write_literal(multi)
+    back = oracle.bool_write(flat(compact, compact.shape[sizes.ndim]), csz.reshape(b), mask.reshape(b, -1),
+                             flat(into, into.shape[sizes.ndim]), sizes.reshape(b))
+    assert np.array_equal(back, flat(want, want.shape[sizes.ndim]))
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_oracle_pad_fill_literal(multi):
+    data, sizes, value, exp, grad = lit.pad_fill_literal(multi)
+    out = oracle.pad_fill(data.reshape(-1, 5), sizes.reshape(-1), value)
+    assert np.array_equal(out.reshape(exp.shape), exp)
+    assert np.allclose(oracle.pad_fill(np.cos(data.astype(np.float64)).reshape(-1, 5), sizes.reshape(-1), 0.0)
+                       .reshape(exp.shape), grad, atol=1e-6)
+
+
+def test_oracle_indices_from_mask_literals():
+    for mask, sizes, rows, width in lit.indices_from_mask_literals():
+        out, s = oracle.indices_from_mask(mask, sizes)
+        assert s.tolist() == [len(r) for r in rows]
+        assert out.shape[1] == max(len(r) for r in rows)          # the oracle's width is the max count
+        for i, r in enumerate(rows):
+            assert out[i, :len(r)].tolist() == r
+
+
+def test_oracle_mapping_grads_and_multi_batch_literal():
+    src, si, di, counts, into, exp = lit.mapping_literal()
+    g_src, g_into = lit.mapping_grads_literal()
+    up = np.cos(exp.astype(np.float64))
+    # d(src): accumulate-scatter of the upstream gradient read at the destination slots (batched_index_mapping_op.py:54-81)
+    got_src = oracle.map_pairs(up, di, si, counts, np.zeros_like(src, dtype=np.float64), accumulate=True)
+    assert np.allclose(got_src, g_src, atol=1e-6)
+    assert np.allclose(oracle.insert_const(0.0, di, counts, up), g_into, atol=1e-6)
+    src, si, di, counts, into, exp, g_src, g_into = lit.mapping_multi_batch_literal()
+    out = oracle.map_pairs(src.reshape(4, 3, 2), si.reshape(4, 3), di.reshape(4, 3), counts.reshape(4), into.reshape(4, 4, 2))
+    assert np.array_equal(out.reshape(exp.shape), exp)
+
+
+def test_cpu_product_paths_on_the_new_literals():
+    # the CPU paths the reference itself has (RaggedBatch pad fill, boolean compaction / write-back, indices from mask,
+    # combine_data shapes) against the same literals
+    for multi in (False, True):
+        data, sizes, value, exp, _ = lit.pad_fill_literal(multi)
+        rb = RaggedBatch(torch.from_numpy(data.copy()), sample_sizes=torch.from_numpy(sizes))
+        assert np.array_equal(rb.with_padded_set_to(value).tensor.numpy(), exp)
+        data, sizes, mask, exp, out_sizes = (lit.bool_index_multi_literal if multi else lit.bool_index_simple_literal)()
+        rb = RaggedBatch(torch.from_numpy(data), sample_sizes=torch.from_numpy(sizes))
+        mrb = RaggedBatch(torch.from_numpy(mask), sample_sizes=torch.from_numpy(sizes))
+        got = batched_bool_indexing(rb, mrb)
+        assert np.array_equal(got.tensor.numpy(), exp) and np.array_equal(got.sample_sizes.numpy(), out_sizes)
+        compact, csz, mask, sizes, into, want = lit.bool_write_literal(multi)
+        back = batched_bool_indexing_write(RaggedBatch(torch.from_numpy(compact), sample_sizes=torch.from_numpy(csz)),
+                                           RaggedBatch(torch.from_numpy(mask), sample_sizes=torch.from_numpy(sizes)),
+                                           RaggedBatch(torch.from_numpy(into), sample_sizes=torch.from_numpy(sizes)))
+        assert np.array_equal(back.tensor.numpy(), want)
+    (m1, _, rows1, w1), (m2, s2, rows2, w2) = lit.indices_from_mask_literals()
+    i1 = get_indices_from_mask(torch.from_numpy(m1))
+    assert i1.tensor.dtype == torch.int64 and tuple(i1.tensor.shape) == (4, w1)
+    i2 = get_indices_from_mask(RaggedBatch(torch.from_numpy(m2), sample_sizes=torch.from_numpy(s2)))
+    assert tuple(i2.tensor.shape) == (3, w2)
+    for got, rows in ((i1, rows1), (i2, rows2)):
+        assert got.sample_sizes.tolist() == [len(r) for r in rows]
+        for i, r in enumerate(rows):
+            assert got.tensor[i, :len(r)].tolist() == r
+    sh = lit.combine_literal_shapes()
+    g = torch.Generator().manual_seed(0)
+    flat = [torch.randn(n, generator=g) for n in sh["flat"]]
+    c = combine_data(flat)
+    assert tuple(c.tensor.shape) == (3, 4) and all(torch.equal(c.tensor[i, :n], flat[i]) for i, n in enumerate(sh["flat"]))
+    cn = combine_data([[flat[0], flat[1]], [flat[2]]])
+    assert torch.equal(cn.tensor, c.tensor)
+    extra = [torch.randn(s, generator=g) for s in sh["extra"]]
+    ce = combine_data(extra)
+    assert tuple(ce.tensor.shape) == (2, 3, 4) and torch.equal(ce.tensor[0, :2], extra[0]) and torch.equal(ce.tensor[1], extra[1])
+    grid = [[torch.randn((n,) + sh["grid_inner"], generator=g) for n in row] for row in sh["grid"]]
+    cg = combine_data(grid, flatten_batch_dims=False)
+    assert tuple(cg.batch_shape) == (2, 3) and tuple(cg.shape) == (2, 3, 7, 3, 4)
+    for i, row in enumerate(sh["grid"]):
+        for j, n in enumerate(row):
+            assert int(cg.sample_sizes[i, j]) == n and torch.equal(cg.tensor[i, j, :n], grid[i][j])
+    with pytest.raises(AssertionError):
+        combine_data([grid[0], grid[1] + [torch.randn(3, 3, 4)]], flatten_batch_dims=False)
