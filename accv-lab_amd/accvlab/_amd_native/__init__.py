@@ -11,7 +11,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaccv_hip.so")
+# ACCV_HIP_LIB points experiments (scripts/h1_variants.py) at another build, e.g. the A/B build `make tune`
+LIB_PATH = os.environ.get("ACCV_HIP_LIB") or os.path.join(_HERE, "libaccv_hip.so")
 
 OK = 0
 HM_CLEAR = 1
@@ -19,6 +20,8 @@ HM_COUNTS_I64 = 2
 HM_SMALL_RADII = 4
 HM_WRITE_THROUGH = 8
 HM_GROUP_BOXES_GIVEN = 16
+HM_TILE_ROWS_16 = 32
+HM_TILE_ROWS_8 = 64
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -33,6 +36,7 @@ _u64 = ctypes.c_uint64
 SIGNATURES = {
     "accv_last_error": (ctypes.c_char_p, []),
     "accv_version": (_i, []),
+    "accv_draw_heatmap_last_dispatch": (ctypes.c_char_p, []),
     "accv_draw_heatmap_flat_workspace_bytes": (_sz, [_i, _i]),
     "accv_draw_heatmap_flat_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _u, _vp, _sz, _vp]),
     "accv_draw_heatmap_batched_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _u, _vp]),
@@ -68,12 +72,55 @@ SIGNATURES = {
     "accv_polyline_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "accv_polyline_sample_boxes": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
-# not in the public header (bench / profiling knobs)
+# not in the public header and not in the shipped library: the knob setter of the A/B build (make -C csrc tune)
 _PRIVATE = {
     "accv_tune_set": (_i, [ctypes.c_char_p, _i]),
 }
 
 _lib = None
+_handle = None
+
+try:  # METH_FASTCALL trampoline (csrc_host/fastcall.cpp): same exported functions, ~0.3 us per call instead of ~4 us
+    from . import _fastcall
+except ImportError:  # pragma: no cover - the ctypes path is complete on its own
+    _fastcall = None
+if os.environ.get("ACCV_NO_FASTCALL") == "1":
+    _fastcall = None
+
+_INT_CLASS = (_vp, _i, _u, _sz, _i64, _ll, _u64)
+
+
+def _fast_entry(fn, res, args):
+    """A callable with the C argument order that goes through the trampoline, or None when the signature is not
+    eligible (non-int result, string arguments, a float count other than 0 or 2)."""
+    if _fastcall is None or res is not _i or len(args) > 18:
+        return None
+    floats = [k for k, a in enumerate(args) if a is _f]
+    if any(a is not _f and a not in _INT_CLASS for a in args):
+        return None
+    addr = ctypes.cast(fn, ctypes.c_void_p).value
+    if not floats and len(args) <= 16:
+        import functools
+        return functools.partial(_fastcall.call_ints, addr)
+    if len(floats) == 2 and floats[1] == floats[0] + 1 and len(args) - 2 <= 16:
+        f0, call = floats[0], _fastcall.call_f2
+        return lambda *a: call(addr, a[f0], a[f0 + 1], *a[:f0], *a[f0 + 2:])
+    return None
+
+
+class _Lib:
+    """Attribute access by exported name; hot entry points resolve to the trampoline, everything else to ctypes."""
+
+    def __init__(self, handle):
+        self._ctypes = handle
+
+    def __getattr__(self, name):
+        fn = getattr(self._ctypes, name)
+        sig = SIGNATURES.get(name) or _PRIVATE.get(name)
+        fast = _fast_entry(fn, *sig) if sig else None
+        fn = fast or fn
+        setattr(self, name, fn)       # cached: __getattr__ is not consulted again
+        return fn
 
 
 class AccvNativeError(RuntimeError):
@@ -81,8 +128,8 @@ class AccvNativeError(RuntimeError):
     RuntimeError behaviour)."""
 
 
-def lib() -> ctypes.CDLL:
-    global _lib
+def lib() -> "_Lib":
+    global _lib, _handle
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(
@@ -92,11 +139,20 @@ def lib() -> ctypes.CDLL:
         handle = ctypes.CDLL(LIB_PATH)
         for table in (SIGNATURES, _PRIVATE):
             for name, (res, args) in table.items():
+                if table is _PRIVATE and not hasattr(handle, name):
+                    continue
                 fn = getattr(handle, name)
                 fn.restype = res
                 fn.argtypes = args
-        _lib = handle
+        _handle = handle
+        _lib = _Lib(handle)
     return _lib
+
+
+def ctypes_lib() -> ctypes.CDLL:
+    """The plain ctypes handle (symbol-table checks, tests)."""
+    lib()
+    return _handle
 
 
 def check(status: int, what: str = "") -> None:
@@ -106,7 +162,18 @@ def check(status: int, what: str = "") -> None:
 
 
 def tune_set(key: str, value: int) -> None:
-    check(lib().accv_tune_set(key.encode(), int(value)), "accv_tune_set")
+    """Kernel-variant knobs exist only in the A/B build (``make -C accv-lab_amd/csrc tune`` + ``ACCV_HIP_LIB``)."""
+    handle = ctypes_lib()
+    if not hasattr(handle, "accv_tune_set"):
+        raise AccvNativeError("this libaccv_hip.so has no tuning knobs (shipped build); use the public flags "
+                              "(tile_rows=, write_through=, small_radii=) or load the A/B build via ACCV_HIP_LIB")
+    check(handle.accv_tune_set(key.encode(), int(value)), "accv_tune_set")
+
+
+def last_dispatch() -> str:
+    """Kernel instantiation + launch geometry of the last draw_heatmap call on this thread."""
+    s = ctypes_lib().accv_draw_heatmap_last_dispatch()
+    return s.decode() if s else ""
 
 
 def stream_ptr(device) -> int:

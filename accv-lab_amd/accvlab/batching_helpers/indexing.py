@@ -121,7 +121,12 @@ def _run(fn, *args):
         for a in args:
             if isinstance(a, torch.Tensor) and a.requires_grad:
                 return fn.apply(*args)
-    return fn.forward(_NoCtx(), *args)
+    out = fn.forward(_NoCtx(), *args)
+    # the binding allocates its result with requires_grad = input.requires_grad (as the reference's torch::full does);
+    # under torch.no_grad() Function.apply would hand back a tensor that does NOT require grad -> same here
+    if isinstance(out, torch.Tensor) and out.requires_grad:
+        out.requires_grad_(False)
+    return out
 
 
 class _NoCtx:

@@ -24,11 +24,18 @@ _cache: dict = {}
 
 
 def _cached(key, make):
+    """Device constants (sample fractions, full-size counts) shared by every later call — on ANY stream.  The tensor is
+    created on the stream that is current at the first call, so that stream is drained once before the tensor is
+    published; while a stream is being captured into a graph nothing is cached (no synchronisation allowed there)."""
     t = _cache.get(key)
     if t is None:
+        t = make()
+        if torch.cuda.is_current_stream_capturing():
+            return t
+        torch.cuda.current_stream(t.device).synchronize()
         if len(_cache) > 64:
             _cache.clear()
-        t = _cache[key] = make()
+        _cache[key] = t
     return t
 
 

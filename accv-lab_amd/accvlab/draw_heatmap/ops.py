@@ -16,6 +16,19 @@ import torch
 from .. import _amd_native as _nat
 
 
+# OR-ed into the flags of every draw_heatmap / draw_heatmap_batched call: lets the GPU test-suite run each test against
+# every kernel instantiation the public hints can select (tests/test_draw_heatmap_gpu.py); 0 in production
+_FORCED_FLAGS = 0
+
+
+def _hint_flags(clear: bool, small_radii: bool, write_through: bool, tile_rows) -> int:
+    if tile_rows not in (None, 8, 16):
+        raise RuntimeError("tile_rows must be None, 8 or 16")
+    return (_nat.HM_CLEAR if clear else 0) | (_nat.HM_SMALL_RADII if small_radii else 0) | \
+        (_nat.HM_WRITE_THROUGH if write_through else 0) | \
+        (_nat.HM_TILE_ROWS_16 if tile_rows == 16 else _nat.HM_TILE_ROWS_8 if tile_rows == 8 else 0) | _FORCED_FLAGS
+
+
 def _require(cond: bool, msg: str) -> None:
     if not cond:
         raise RuntimeError(msg)
@@ -52,6 +65,7 @@ def draw_heatmap(
     clear: bool = False,
     small_radii: bool = False,
     write_through: bool = False,
+    tile_rows: Optional[int] = None,
 ) -> None:
     """Draw N Gaussians into ``heatmaps[P,H,W]`` (fp32, in place, element-wise max).
 
@@ -99,8 +113,7 @@ def draw_heatmap(
         status = lib.accv_draw_heatmap_flat_f32(
             heatmaps.data_ptr(), planes, height, width, centers.data_ptr(), radii.data_ptr(),
             heatmap_idxes.data_ptr(), n, float(diameter_to_sigma_factor), float(k_scale),
-            (_nat.HM_CLEAR if clear else 0) | (_nat.HM_SMALL_RADII if small_radii else 0) |
-            (_nat.HM_WRITE_THROUGH if write_through else 0), ws.data_ptr(), ws_bytes,
+            _hint_flags(clear, small_radii, write_through, tile_rows), ws.data_ptr(), ws_bytes,
             _nat.stream_ptr(heatmaps.device))
         # the workspace is only used by kernels already enqueued on the current stream; the caching
         # allocator re-issues it stream-ordered, so dropping the reference here is safe
@@ -118,6 +131,7 @@ def draw_heatmap_batched(
     clear: bool = False,
     small_radii: bool = False,
     write_through: bool = False,
+    tile_rows: Optional[int] = None,
 ) -> None:
     """Draw a ragged batch of Gaussians (in place, element-wise max).
 
@@ -131,6 +145,7 @@ def draw_heatmap_batched(
         clear: (extension) fused zero-fill + draw in one write-only pass.
         small_radii: (extension) performance hint for point-like objects, see :func:`draw_heatmap`.
         write_through: (extension) store-policy hint for dense launches over huge maps, see :func:`draw_heatmap`.
+        tile_rows: (extension) tile-height hint (8 or 16), see :func:`draw_heatmap`.
 
     Only ``centers.sample_sizes`` decides how many leading objects of a sample are drawn; padded slots are
     never touched.  Reference: funtions/draw_heatmap_batched.py:27-84 -> draw_heatmap_batched_launcher /
@@ -196,8 +211,8 @@ def draw_heatmap_batched(
     if labels_t is not None and num_classes == 0:
         return
 
-    flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0) | \
-        (_nat.HM_SMALL_RADII if small_radii else 0) | (_nat.HM_WRITE_THROUGH if write_through else 0)
+    flags = _hint_flags(clear, small_radii, write_through, tile_rows) | \
+        (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0)
     with _nat.device_guard(heatmap.device):
         status = _nat.lib().accv_draw_heatmap_batched_f32(
             heatmap.data_ptr(), batch, num_classes, height, width, centers_t.data_ptr(), radii_t.data_ptr(),

@@ -65,3 +65,64 @@ def all_gather_heatmaps(local: torch.Tensor, total_frames: Optional[int] = None,
     if total_frames is not None and out.shape[0] != total_frames:
         raise RuntimeError(f"gathered {out.shape[0]} frames, expected {total_frames}")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Control flow of a frame-sharded, one-process-per-GPU job.  bench.py is built from these functions, and the
+# world-size-2 gloo test (tests/test_sharding_gloo.py) runs the SAME functions on CPU.
+def rank_layout(env=None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world) as set by ``python -m torch.distributed.run`` (1-process defaults otherwise)."""
+    import os
+
+    env = os.environ if env is None else env
+    return int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), int(env.get("WORLD_SIZE", "1"))
+
+
+def rank_seed(base_seed: int, rank: int) -> int:
+    """Every rank draws its OWN frames (weak scaling): seed = base + rank."""
+    return int(base_seed) + int(rank)
+
+
+def init_process_group(world: int, backend: str = "nccl", device=None):
+    """``torch.distributed`` module with an initialised default group, or None for a single process.  ``nccl`` is
+    RCCL on ROCm (one rank per GPU); ``gloo`` lets several ranks share a device or run on CPU (tests, rehearsals)."""
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return dist
+
+
+def job_barrier(dist, sync=None) -> None:
+    """device sync + barrier + device sync: the bracket of a timed region (bench contract)."""
+    if sync is not None:
+        sync()
+    if dist is not None:
+        dist.barrier()
+    if sync is not None:
+        sync()
+
+
+def timed_steps(step, steps: int, dist=None, sync=None, clock=None) -> float:
+    """Run ``step()`` exactly ``steps`` times between two ``job_barrier`` brackets; wall milliseconds per step of THIS
+    rank (reduce with :func:`max_over_ranks`)."""
+    import time
+
+    clock = clock or time.perf_counter
+    job_barrier(dist, sync)
+    t0 = clock()
+    for _ in range(steps):
+        step()
+    job_barrier(dist, sync)
+    return (clock() - t0) * 1e3 / max(1, steps)
+
+
+def job_throughput(units_per_rank: int, world: int, ms_per_step_max: float) -> float:
+    """Whole-job units per second: every rank processed ``units_per_rank`` per step, the step took the slowest
+    rank's time."""
+    return world * units_per_rank / (ms_per_step_max * 1e-3)

@@ -68,12 +68,18 @@ def _gpu(points, distances, p_sizes, d_sizes, relative, want_points, want_length
         return out_p, out_l
     points = points.contiguous()
     distances = distances.contiguous() if distances is not None else None
+    # ONE width flag covers both count arrays in the C-ABI: take it from whichever is present and convert the other if
+    # it differs (an int64 array read as int32 would silently truncate the number of samples)
     c64 = 0
-    if p_sizes is not None:
-        p_sizes = p_sizes.contiguous()
-        c64 = 1 if p_sizes.dtype == torch.int64 else 0
-    if d_sizes is not None:
-        d_sizes = d_sizes.contiguous()
+    present = [t for t in (p_sizes, d_sizes) if t is not None]
+    if present:
+        wide = any(t.dtype == torch.int64 for t in present)
+        want = torch.int64 if wide else torch.int32
+        c64 = 1 if wide else 0
+        if p_sizes is not None:
+            p_sizes = p_sizes.to(want).contiguous()
+        if d_sizes is not None:
+            d_sizes = d_sizes.to(want).contiguous()
     with _nat.device_guard(points.device):
         sb = lib.accv_polyline_scratch_bytes(b, pmax, code)
         scratch = torch.empty(sb, dtype=torch.uint8, device=points.device) if sb else None

@@ -394,6 +394,23 @@ def _coalesced_d2h(job: _Job, lib, small: np.ndarray, sdev: torch.device, side) 
     return True
 
 
+def _abandon(job: _Job) -> None:
+    """A copy failed half way: wait for whatever was already enqueued on the side streams (the completion event may
+    never have been recorded), then hand the staging blocks back."""
+    try:
+        for ev in job.events:
+            ev.synchronize()
+        devs = set(job.source_events)
+        if job.device.type == "cuda":
+            devs.add(job.device.index)
+        for i in devs:
+            side = _side_streams.get(int(i))
+            if side is not None:
+                side.synchronize()
+    finally:
+        job.release_staging()
+
+
 def _rebuild_without_gc(tree):
     """Build the output structure with the cyclic collector paused.  A 10k-leaf result is 12k fresh GC-tracked
     objects; with the collector running, the generation-0 passes it triggers every 700 allocations promote the
@@ -420,19 +437,32 @@ class AsyncCopyHandle:
         self._result = None
         self._consumed = False
 
+    def _worker_result(self) -> None:
+        """Re-raise a worker exception — after the transfers that were already enqueued have drained and the arena
+        blocks acquired before the failure went back (otherwise they would leak for the life of the process, and the
+        keep-alives of an active DMA would be dropped with the handle)."""
+        if self._future is None:
+            return
+        try:
+            self._future.result()
+        except BaseException:
+            _abandon(self._job)
+            raise
+
     def _finish(self) -> None:
-        if self._future is not None:
-            self._future.result()            # re-raises worker exceptions
-        for ev in self._job.events:
-            ev.synchronize()
-        self._job.release_staging()
+        self._worker_result()
+        try:
+            for ev in self._job.events:
+                ev.synchronize()
+        finally:
+            self._job.release_staging()
 
     def ready(self) -> bool:
         """True once the copy has completed (non-blocking).  Raises if the copy failed."""
         if self._future is not None:
             if not self._future.done():
                 return False
-            self._future.result()
+            self._worker_result()
         if all(ev.query() for ev in self._job.events):
             self._job.release_staging()
             return True
@@ -507,5 +537,9 @@ def start_copy(data, device, *, use_pinned_staging: bool = True, pack_cpu_tensor
         job.source_events[int(dev_index)] = ev
     if use_background_thread:
         return AsyncCopyHandle(job, _executor().submit(_run, job))
-    _run(job)  # inline: exceptions propagate from start_copy (reference :1151-1153)
+    try:
+        _run(job)  # inline: exceptions propagate from start_copy (reference :1151-1153)
+    except BaseException:
+        _abandon(job)
+        raise
     return AsyncCopyHandle(job, None)

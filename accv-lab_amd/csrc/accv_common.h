@@ -22,7 +22,14 @@ inline int check_launch(const char* what)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// runtime tuning knobs (bench / A-B experiments only; defaults are the shipped configuration)
+char* dispatch_buffer();  // thread-local, 256 bytes: description of the last draw_heatmap dispatch
+
+#ifdef ACCV_TUNE_BUILD
+// runtime tuning knobs: ONLY in the A/B build (make tune -> libaccv_hip_tune.so, scripts/h1_variants.py --alt-lib);
+// the shipped library has no knob table, no mutex and no string look-ups on its dispatch path
 int tune_get(const char* key, int fallback);
+#else
+inline int tune_get(const char*, int fallback) { return fallback; }
+#endif
 
 }  // namespace accv

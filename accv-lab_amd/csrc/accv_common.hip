@@ -1,4 +1,4 @@
-// Error reporting, version and tuning knobs of libaccv_hip.so.
+// Error reporting, version and the last-dispatch string of libaccv_hip.so (+ the knob table of the A/B build).
 #include "accv_common.h"
 
 #include <cstring>
@@ -23,6 +23,13 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
+char* dispatch_buffer()
+{
+    static thread_local char buf[256] = {0};
+    return buf;
+}
+
+#ifdef ACCV_TUNE_BUILD
 static std::mutex g_tune_mutex;
 static std::map<std::string, int>& tune_map()
 {
@@ -36,6 +43,7 @@ int tune_get(const char* key, int fallback)
     auto it = tune_map().find(key);
     return it == tune_map().end() ? fallback : it->second;
 }
+#endif
 
 }  // namespace accv
 
@@ -45,7 +53,10 @@ const char* accv_last_error(void) { return accv::error_buffer(); }
 
 int accv_version(void) { return 100; }
 
-// Not part of the public header: used by bench.py / profiling scripts for in-process A/B of kernel variants.
+const char* accv_draw_heatmap_last_dispatch(void) { return accv::dispatch_buffer(); }
+
+#ifdef ACCV_TUNE_BUILD
+// A/B build only (not in the public header, not in the shipped library): in-process selection of kernel variants.
 int accv_tune_set(const char* key, int value)
 {
     if (!key) return ACCV_EINVAL;
@@ -53,4 +64,5 @@ int accv_tune_set(const char* key, int value)
     accv::tune_map()[key] = value;
     return ACCV_OK;
 }
+#endif
 }

@@ -610,6 +610,12 @@ __global__ __launch_bounds__(64) void group_boxes_kernel(const float2* __restric
     if (threadIdx.x == 0) boxes[gid] = make_float4(x0, y0, x1, y1);
 }
 
+void note_dispatch(const char* kernel, int px, int r, bool clear, int sm, const dim3& grid, const dim3& block)
+{
+    snprintf(accv::dispatch_buffer(), 256, "%s<PX=%d,R=%d,CLEAR=%d,SM=%d> grid(%u,%u,%u) block(%u)", kernel, px, r, clear ? 1 : 0,
+             sm, grid.x, grid.y, grid.z, block.x);
+}
+
 int launch_splat_small(SplatParams p, long long planes, bool clear, int sm, hipStream_t stream)
 {
     p.tiles_x = (p.W + 127) / 128;
@@ -635,6 +641,7 @@ int launch_splat_small(SplatParams p, long long planes, bool clear, int sm, hipS
         else
             hipLaunchKernelGGL((splat_small_kernel<false, 0>), grid, dim3(64), 0, stream, p);
     }
+    note_dispatch("splat_small_kernel", 4, 8, clear, sm >= 2 ? 4 : 0, grid, dim3(64));
     return accv::check_launch("draw_heatmap small-splat kernel");
 }
 
@@ -790,6 +797,8 @@ __global__ void fill_tail_kernel(float* __restrict__ dst, size_t n, float value)
     if (i < n) dst[i] = value;
 }
 
+// store mode SM: 0 plain, 4 write-through non-temporal (sc1 nt).  (The A/B build also instantiates 1 = non-temporal and
+// 2 = write-through, and 4-wave workgroups: -DACCV_TUNE_BUILD.)
 template <int PX, int R, int WPG = kWavesPerGroup>
 int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_t stream)
 {
@@ -815,16 +824,20 @@ int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_
             hipLaunchKernelGGL((splat_kernel<PX, R, false, SMV, WPG>), grid, block, 0, stream, p);   \
     } while (0)
     if constexpr (PX == 4) {
-        switch (sm) {  // store mode: 0 plain, 1 non-temporal, 2 write-through (sc1), 4 write-through non-temporal
+        switch (sm) {
+#ifdef ACCV_TUNE_BUILD
             case 1: ACCV_LAUNCH_SM(1); break;
             case 2: ACCV_LAUNCH_SM(2); break;
+#endif
             case 4: ACCV_LAUNCH_SM(4); break;
-            default: ACCV_LAUNCH_SM(0); break;
+            default: sm = 0; ACCV_LAUNCH_SM(0); break;
         }
     } else {
+        sm = 0;
         ACCV_LAUNCH_SM(0);
     }
 #undef ACCV_LAUNCH_SM
+    note_dispatch("splat_kernel", PX, R, clear, sm, grid, block);
     return accv::check_launch("draw_heatmap splat kernel");
 }
 
@@ -832,27 +845,33 @@ int dispatch_splat(SplatParams p, long long planes, bool clear, unsigned flags, 
 {
     const bool small_hint = (flags & ACCV_HM_SMALL_RADII) != 0;
     const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.hm) & 15u) == 0);
-    // Store policy and tile height, from in-process A/B runs of the end-of-round kernel on ten boxes
-    // (profiles/r01_h1_ab_rows_store_policy.log): plain stores everywhere (write-through / non-temporal stores, which
-    // paid +2..8 % on the mid-round kernel, now cost 0..7 %), and for fused-clear launches far larger than L2 +
-    // Infinity Cache a 128 x 32 tile (R = 16: -4..-7 % on the slower boxes, +-0.5 % on the fastest); in-place launches
-    // and small maps keep 128 x 16 (more waves, less read-modify-write per touched tile).  "hm_nt" / "hm_rows" override.
+    // Store policy and tile height, from in-process A/B runs on ten boxes (profiles/r01_h1_ab_rows_store_policy.log):
+    // plain stores everywhere unless the caller asks for write-through ones, and for fused-clear launches far larger than
+    // L2 + Infinity Cache a 128 x 32 tile (R = 16: -4..-7 % on the slower boxes, +-0.5 % on the fastest); in-place
+    // launches and small maps keep 128 x 16 (more waves, less read-modify-write per touched tile).  The caller's
+    // ACCV_HM_TILE_ROWS_* hints override the size rule.  No knob table, mutex or string look-up on this path.
     const size_t total_bytes = (size_t)planes * p.H * p.W * sizeof(float);
     const bool plane_fits_rsrc = (size_t)p.H * p.W * sizeof(float) < ((size_t)1 << 31);
     int nt = accv::tune_get("hm_nt", -1);
     if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;
     if (nt >= 2 && !plane_fits_rsrc) nt = 0;
     int rows = accv::tune_get("hm_rows", -1);
-    if (rows < 0) rows = (clear && total_bytes > ((size_t)128 << 20)) ? 16 : 8;
-    // tuning knobs exist for in-process A/B runs (scripts/h1_variants.py); the defaults are the shipped configuration
+    if (rows < 0) {
+        if (flags & ACCV_HM_TILE_ROWS_16)
+            rows = 16;
+        else if (flags & ACCV_HM_TILE_ROWS_8)
+            rows = 8;
+        else
+            rows = (clear && total_bytes > ((size_t)128 << 20)) ? 16 : 8;
+    }
     if (!p.labels) p.labels = p.radii;  // branch-free candidate loads: always a readable array (ignored when cls < 0)
     if (!vec4) return launch_splat<1, 8>(p, planes, clear, 0, stream);
-    // point-like objects (caller's ACCV_HM_SMALL_RADII hint; "hm_small" 0/1 overrides for tests and A/B runs)
-    const int small = accv::tune_get("hm_small", -1);
+    const int small = accv::tune_get("hm_small", -1);   // point-like objects: the caller's ACCV_HM_SMALL_RADII hint
     if (small > 0 || (small < 0 && small_hint)) return launch_splat_small(p, planes, clear, nt, stream);
-    const int wpg = accv::tune_get("hm_wpg", kWavesPerGroup);
     if (rows == 16) return launch_splat<4, 16>(p, planes, clear, nt, stream);
-    if (wpg == 4) return launch_splat<4, 8, 4>(p, planes, clear, nt, stream);
+#ifdef ACCV_TUNE_BUILD
+    if (accv::tune_get("hm_wpg", kWavesPerGroup) == 4) return launch_splat<4, 8, 4>(p, planes, clear, nt, stream);
+#endif
     return launch_splat<4, 8>(p, planes, clear, nt, stream);
 }
 
@@ -1030,7 +1049,7 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
     if (used == 0 || tiles == 0) return ACCV_OK;
     if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: %lld tiles exceed the grid limit", tiles);
     int nt = accv::tune_get("hm_nt", -1);
-    if (nt < 0) nt = 0;   // same store policy as the single-scale path
+    if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;   // same store policy as the single-scale path
     const dim3 grid((unsigned)tiles), block(64);
     if (clear) {
         if (nt >= 2)
@@ -1043,6 +1062,7 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
         else
             hipLaunchKernelGGL((splat_multi_kernel<false, 0>), grid, block, 0, stream, mp);
     }
+    note_dispatch("splat_multi_kernel", 4, 8, clear, nt >= 2 ? 4 : 0, grid, block);
     return accv::check_launch("draw_heatmap multi-scale splat kernel");
 }
 
@@ -1122,7 +1142,7 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
                            reinterpret_cast<const float2*>(points_xy), num_points, n_groups, total_groups,
                            static_cast<float4*>(workspace));
     int nt = accv::tune_get("hm_nt", -1);
-    if (nt < 0) nt = 0;
+    if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;
     const dim3 grid((unsigned)tiles), block(64);
     if (clear) {
         if (nt >= 2)
@@ -1135,6 +1155,7 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
         else
             hipLaunchKernelGGL((splat_points_multi_kernel<false, 0>), grid, block, 0, stream, mp);
     }
+    note_dispatch("splat_points_multi_kernel", 4, 8, clear, nt >= 2 ? 4 : 0, grid, block);
     return accv::check_launch("draw_heatmap multi-scale point splat kernel");
 }
 

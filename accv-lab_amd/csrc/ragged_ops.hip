@@ -76,74 +76,99 @@ __device__ __forceinline__ long long wrap_index(long long j, long long width, in
 
 enum Mode { kGather = 0, kScatter = 1, kMapPairs = 2 };
 
-// one thread per (sample i, slot j, vector v); v fastest => a wave covers consecutive vectors of a row
+// Launch geometry shared by the row kernels: NO per-thread division.  A row = one (sample i, slot j) pair of `row_vecs`
+// vectors.  2^lg lanes work on a row (consecutive lanes = consecutive vectors: coalesced), a 256-thread workgroup
+// covers 256 >> lg consecutive slots of ONE sample: blockIdx.x = slot group, blockIdx.y = sample (looped when the
+// batch exceeds the grid's y extent).  For the row sizes of this path (<= 4 KB) every thread moves exactly one
+// vector, i.e. every wave issues ONE load and ONE store — the pattern that streams fastest on this chip.
+struct RowGeom {
+    int lg;  // log2(lanes per row), 0..8
+};
+__device__ __forceinline__ bool row_of_thread(const RowGeom g, long long w_idx, long long& j, int& v0, int& lanes)
+{
+    lanes = 1 << g.lg;
+    v0 = (int)threadIdx.x & (lanes - 1);
+    j = (long long)blockIdx.x * (256 >> g.lg) + ((int)threadIdx.x >> g.lg);
+    return j < w_idx;
+}
+
 template <int VB, int MODE>
-__global__ __launch_bounds__(256) void copy_rows_kernel(const RaggedDesc d, const void* __restrict__ src_,
+__global__ __launch_bounds__(256) void copy_rows_kernel(const RaggedDesc d, const RowGeom g, const void* __restrict__ src_,
                                                         void* __restrict__ dst_)
 {
     using V = typename VecOf<VB>::type;
     const V* src = static_cast<const V*>(src_);
     V* dst = static_cast<V*>(dst_);
-    const long long total = d.batch * d.w_idx * d.row_vecs;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const long long pair = t / d.row_vecs, v = t - pair * d.row_vecs;
-        const long long i = pair / d.w_idx, j = pair - i * d.w_idx;
-        if (j >= load_int(d.counts, i, d.counts_i64)) continue;
+    long long j;
+    int v0, lanes;
+    if (!row_of_thread(g, d.w_idx, j, v0, lanes)) return;
+    for (long long i = blockIdx.y; i < d.batch; i += gridDim.y) {
+        // the count (uniform: scalar load) and the index of this slot are fetched together; slots behind the count hold
+        // anything (the reference fills them with out-of-range junk) and are never interpreted
         const long long slot = i * d.idx_stride + j;
+        const long long a = load_int(d.idx_a, slot, d.idx_i64);
+        const long long b = MODE == kMapPairs ? load_int(d.idx_b, slot, d.idx_i64) : 0;
+        if (j >= load_int(d.counts, i, d.counts_i64)) continue;
+        long long from, to;
         if (MODE == kGather) {
-            const long long s = wrap_index(load_int(d.idx_a, slot, d.idx_i64), d.w_src, d.err);
+            const long long s = wrap_index(a, d.w_src, d.err);
             if (s < 0) continue;
-            dst[(i * d.w_idx + j) * d.row_vecs + v] = src[(i * d.w_src + s) * d.row_vecs + v];
+            from = (i * d.w_src + s) * d.row_vecs;
+            to = (i * d.w_idx + j) * d.row_vecs;
         } else if (MODE == kScatter) {
-            const long long o = wrap_index(load_int(d.idx_a, slot, d.idx_i64), d.w_dst, d.err);
+            const long long o = wrap_index(a, d.w_dst, d.err);
             if (o < 0) continue;
-            dst[(i * d.w_dst + o) * d.row_vecs + v] = src[(i * d.w_idx + j) * d.row_vecs + v];
+            from = (i * d.w_idx + j) * d.row_vecs;
+            to = (i * d.w_dst + o) * d.row_vecs;
         } else {
-            const long long s = wrap_index(load_int(d.idx_a, slot, d.idx_i64), d.w_src, d.err);
-            const long long o = wrap_index(load_int(d.idx_b, slot, d.idx_i64), d.w_dst, d.err);
+            const long long s = wrap_index(a, d.w_src, d.err);
+            const long long o = wrap_index(b, d.w_dst, d.err);
             if (s < 0 || o < 0) continue;
-            dst[(i * d.w_dst + o) * d.row_vecs + v] = src[(i * d.w_src + s) * d.row_vecs + v];
+            from = (i * d.w_src + s) * d.row_vecs;
+            to = (i * d.w_dst + o) * d.row_vecs;
         }
+        for (long long v = v0; v < d.row_vecs; v += lanes) dst[to + v] = src[from + v];
     }
 }
 
 // gather that also writes the filler: dst[i, j, :] = src[i, idx[i,j], :] for valid (i, j), `pattern` elsewhere, so the
 // caller hands over an UNINITIALISED result (one launch instead of torch::full + gather, cpp:82-85)
 template <int VB>
-__global__ __launch_bounds__(256) void gather_fill_kernel(const RaggedDesc d, const void* __restrict__ src_,
+__global__ __launch_bounds__(256) void gather_fill_kernel(const RaggedDesc d, const RowGeom g, const void* __restrict__ src_,
                                                           void* __restrict__ dst_, typename VecOf<VB>::type pattern)
 {
     using V = typename VecOf<VB>::type;
     const V* src = static_cast<const V*>(src_);
     V* dst = static_cast<V*>(dst_);
-    const long long total = d.batch * d.w_idx * d.row_vecs;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const long long pair = t / d.row_vecs, v = t - pair * d.row_vecs;
-        const long long i = pair / d.w_idx, j = pair - i * d.w_idx;
-        V val = pattern;
-        if (j < load_int(d.counts, i, d.counts_i64)) {
-            const long long s = wrap_index(load_int(d.idx_a, i * d.idx_stride + j, d.idx_i64), d.w_src, d.err);
-            if (s >= 0) val = src[(i * d.w_src + s) * d.row_vecs + v];
-        }
-        dst[t] = val;
+    long long j;
+    int v0, lanes;
+    if (!row_of_thread(g, d.w_idx, j, v0, lanes)) return;
+    for (long long i = blockIdx.y; i < d.batch; i += gridDim.y) {
+        const long long a = load_int(d.idx_a, i * d.idx_stride + j, d.idx_i64);
+        long long s = -1;
+        if (j < load_int(d.counts, i, d.counts_i64)) s = wrap_index(a, d.w_src, d.err);
+        const long long from = (i * d.w_src + max(s, 0ll)) * d.row_vecs, to = (i * d.w_idx + j) * d.row_vecs;
+        for (long long v = v0; v < d.row_vecs; v += lanes) dst[to + v] = s >= 0 ? src[from + v] : pattern;
     }
 }
 
 // dst[i, idx[i,j], :] = pattern
 template <int VB>
-__global__ __launch_bounds__(256) void insert_const_kernel(const RaggedDesc d, void* __restrict__ dst_,
+__global__ __launch_bounds__(256) void insert_const_kernel(const RaggedDesc d, const RowGeom g, void* __restrict__ dst_,
                                                            typename VecOf<VB>::type pattern)
 {
     using V = typename VecOf<VB>::type;
     V* dst = static_cast<V*>(dst_);
-    const long long total = d.batch * d.w_idx * d.row_vecs;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const long long pair = t / d.row_vecs, v = t - pair * d.row_vecs;
-        const long long i = pair / d.w_idx, j = pair - i * d.w_idx;
+    long long j;
+    int v0, lanes;
+    if (!row_of_thread(g, d.w_idx, j, v0, lanes)) return;
+    for (long long i = blockIdx.y; i < d.batch; i += gridDim.y) {
+        const long long a = load_int(d.idx_a, i * d.idx_stride + j, d.idx_i64);
         if (j >= load_int(d.counts, i, d.counts_i64)) continue;
-        const long long o = wrap_index(load_int(d.idx_a, i * d.idx_stride + j, d.idx_i64), d.w_dst, d.err);
+        const long long o = wrap_index(a, d.w_dst, d.err);
         if (o < 0) continue;
-        dst[(i * d.w_dst + o) * d.row_vecs + v] = pattern;
+        const long long to = (i * d.w_dst + o) * d.row_vecs;
+        for (long long v = v0; v < d.row_vecs; v += lanes) dst[to + v] = pattern;
     }
 }
 
@@ -151,15 +176,18 @@ __global__ __launch_bounds__(256) void insert_const_kernel(const RaggedDesc d, v
 template <int VB>
 __global__ __launch_bounds__(256) void pad_fill_kernel(void* __restrict__ data_, const void* __restrict__ counts,
                                                        int counts_i64, long long batch, long long width,
-                                                       long long row_vecs, typename VecOf<VB>::type pattern)
+                                                       long long row_vecs, const RowGeom g,
+                                                       typename VecOf<VB>::type pattern)
 {
     using V = typename VecOf<VB>::type;
     V* data = static_cast<V*>(data_);
-    const long long total = batch * width * row_vecs;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const long long pair = t / row_vecs;
-        const long long i = pair / width, j = pair - i * width;
-        if (j >= load_int(counts, i, counts_i64)) data[t] = pattern;
+    long long j;
+    int v0, lanes;
+    if (!row_of_thread(g, width, j, v0, lanes)) return;
+    for (long long i = blockIdx.y; i < batch; i += gridDim.y) {
+        if (j < load_int(counts, i, counts_i64)) continue;
+        const long long to = (i * width + j) * row_vecs;
+        for (long long v = v0; v < row_vecs; v += lanes) data[to + v] = pattern;
     }
 }
 
@@ -198,40 +226,45 @@ __device__ __forceinline__ void atomic_add_16(uint16_t* addr, uint16_t val_bits)
 }
 
 template <int ACC>
-__global__ __launch_bounds__(256) void accumulate_rows_kernel(const RaggedDesc d, const void* __restrict__ src_,
+__global__ __launch_bounds__(256) void accumulate_rows_kernel(const RaggedDesc d, const RowGeom g, const void* __restrict__ src_,
                                                               void* __restrict__ dst_, int pairs)
 {
-    const long long total = d.batch * d.w_idx * d.row_vecs;  // row_vecs == elements per row here
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const long long pair = t / d.row_vecs, k = t - pair * d.row_vecs;
-        const long long i = pair / d.w_idx, j = pair - i * d.w_idx;
-        if (j >= load_int(d.counts, i, d.counts_i64)) continue;
+    long long j;
+    int v0, lanes;
+    if (!row_of_thread(g, d.w_idx, j, v0, lanes)) return;   // row_vecs == elements per row here
+    for (long long i = blockIdx.y; i < d.batch; i += gridDim.y) {
         const long long slot = i * d.idx_stride + j;
-        long long s_elem, o;
+        const long long a = load_int(d.idx_a, slot, d.idx_i64);
+        const long long b = pairs ? load_int(d.idx_b, slot, d.idx_i64) : 0;
+        if (j >= load_int(d.counts, i, d.counts_i64)) continue;
+        long long s_row, o;
         if (pairs) {
-            const long long s = wrap_index(load_int(d.idx_a, slot, d.idx_i64), d.w_src, d.err);
-            o = wrap_index(load_int(d.idx_b, slot, d.idx_i64), d.w_dst, d.err);
+            const long long s = wrap_index(a, d.w_src, d.err);
+            o = wrap_index(b, d.w_dst, d.err);
             if (s < 0 || o < 0) continue;
-            s_elem = (i * d.w_src + s) * d.row_vecs + k;
+            s_row = (i * d.w_src + s) * d.row_vecs;
         } else {
-            o = wrap_index(load_int(d.idx_a, slot, d.idx_i64), d.w_dst, d.err);
+            o = wrap_index(a, d.w_dst, d.err);
             if (o < 0) continue;
-            s_elem = (i * d.w_idx + j) * d.row_vecs + k;
+            s_row = (i * d.w_idx + j) * d.row_vecs;
         }
-        const long long o_elem = (i * d.w_dst + o) * d.row_vecs + k;
-        if (ACC == kF32)
-            atomicAdd(static_cast<float*>(dst_) + o_elem, static_cast<const float*>(src_)[s_elem]);
-        else if (ACC == kF64)
-            atomicAdd(static_cast<double*>(dst_) + o_elem, static_cast<const double*>(src_)[s_elem]);
-        else if (ACC == kI32)
-            atomicAdd(static_cast<int*>(dst_) + o_elem, static_cast<const int*>(src_)[s_elem]);
-        else if (ACC == kI64)
-            atomicAdd(static_cast<unsigned long long*>(dst_) + o_elem,
-                      static_cast<const unsigned long long*>(src_)[s_elem]);
-        else if (ACC == kF16)
-            atomic_add_16<false>(static_cast<uint16_t*>(dst_) + o_elem, static_cast<const uint16_t*>(src_)[s_elem]);
-        else
-            atomic_add_16<true>(static_cast<uint16_t*>(dst_) + o_elem, static_cast<const uint16_t*>(src_)[s_elem]);
+        const long long o_row = (i * d.w_dst + o) * d.row_vecs;
+        for (long long k = v0; k < d.row_vecs; k += lanes) {
+            const long long s_elem = s_row + k, o_elem = o_row + k;
+            if (ACC == kF32)
+                atomicAdd(static_cast<float*>(dst_) + o_elem, static_cast<const float*>(src_)[s_elem]);
+            else if (ACC == kF64)
+                atomicAdd(static_cast<double*>(dst_) + o_elem, static_cast<const double*>(src_)[s_elem]);
+            else if (ACC == kI32)
+                atomicAdd(static_cast<int*>(dst_) + o_elem, static_cast<const int*>(src_)[s_elem]);
+            else if (ACC == kI64)
+                atomicAdd(static_cast<unsigned long long*>(dst_) + o_elem,
+                          static_cast<const unsigned long long*>(src_)[s_elem]);
+            else if (ACC == kF16)
+                atomic_add_16<false>(static_cast<uint16_t*>(dst_) + o_elem, static_cast<const uint16_t*>(src_)[s_elem]);
+            else
+                atomic_add_16<true>(static_cast<uint16_t*>(dst_) + o_elem, static_cast<const uint16_t*>(src_)[s_elem]);
+        }
     }
 }
 
@@ -301,30 +334,42 @@ template <int VB>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const void* __restrict__ flat_, void* __restrict__ dst_,
                                                         const long long* __restrict__ offsets,
                                                         const long long* __restrict__ sizes, long long batch,
-                                                        long long width, long long row_vecs, int unpack)
+                                                        long long width, long long row_vecs, const RowGeom g, int unpack)
 {
     using V = typename VecOf<VB>::type;
-    const long long total = batch * width * row_vecs;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const long long pair = t / row_vecs, v = t - pair * row_vecs;
-        const long long i = pair / width, j = pair - i * width;
+    long long j;
+    int v0, lanes;
+    if (!row_of_thread(g, width, j, v0, lanes)) return;
+    for (long long i = blockIdx.y; i < batch; i += gridDim.y) {
         const bool valid = j < sizes[i];
+        const long long padded = (i * width + j) * row_vecs, flat = (offsets[i] + (valid ? j : 0)) * row_vecs;
         if (!unpack) {
-            V val{};
-            if (valid) val = static_cast<const V*>(flat_)[(offsets[i] + j) * row_vecs + v];
-            static_cast<V*>(dst_)[t] = val;
+            for (long long v = v0; v < row_vecs; v += lanes)
+                static_cast<V*>(dst_)[padded + v] = valid ? static_cast<const V*>(flat_)[flat + v] : V{};
         } else if (valid) {
-            static_cast<V*>(dst_)[(offsets[i] + j) * row_vecs + v] = static_cast<const V*>(flat_)[t];
+            for (long long v = v0; v < row_vecs; v += lanes)
+                static_cast<V*>(dst_)[flat + v] = static_cast<const V*>(flat_)[padded + v];
         }
     }
 }
 
-inline unsigned grid_for(long long total)
+// lanes per row = smallest power of two >= row_vecs (at most 256); grid = (slot groups, samples)
+struct RowLaunch {
+    RowGeom geom;
+    dim3 grid;
+    bool ok;
+};
+inline RowLaunch row_launch(long long batch, long long width, long long row_vecs)
 {
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    if (blocks < 1) blocks = 1;
-    return (unsigned)blocks;
+    RowLaunch r{};
+    int lg = 0;
+    while (lg < 8 && (1ll << lg) < row_vecs) ++lg;
+    r.geom.lg = lg;
+    const long long rows_per_block = 256 >> lg;
+    const long long gx = (width + rows_per_block - 1) / rows_per_block;
+    r.ok = gx <= 0x7fffffffll;
+    r.grid = dim3((unsigned)(gx > 0 ? gx : 1), (unsigned)(batch < 65535 ? (batch > 0 ? batch : 1) : 65535));
+    return r;
 }
 
 inline int pick_vec(long long row_bytes, std::initializer_list<const void*> ptrs)
@@ -376,14 +421,15 @@ int run_copy(int mode, const void* src, void* dst, const void* idx_a, const void
     if (!src || !dst) return accv::fail(ACCV_EINVAL, "%s: null data pointer", who);
     const int vb = pick_vec(row_bytes, {src, dst});
     RaggedDesc d{idx_a, idx_b, counts, batch, w_idx, idx_stride, w_src, w_dst, row_bytes / vb, idx_i64, counts_i64, err};
-    const unsigned grid = grid_for(batch * w_idx * d.row_vecs);
+    const RowLaunch rl = row_launch(batch, w_idx, d.row_vecs);
+    if (!rl.ok) return accv::fail(ACCV_EINVAL, "%s: %lld index slots per sample exceed the grid limit", who, w_idx);
     DISPATCH_VB(vb, {
         if (mode == kGather)
-            hipLaunchKernelGGL((copy_rows_kernel<VB, kGather>), dim3(grid), dim3(256), 0, stream, d, src, dst);
+            hipLaunchKernelGGL((copy_rows_kernel<VB, kGather>), rl.grid, dim3(256), 0, stream, d, rl.geom, src, dst);
         else if (mode == kScatter)
-            hipLaunchKernelGGL((copy_rows_kernel<VB, kScatter>), dim3(grid), dim3(256), 0, stream, d, src, dst);
+            hipLaunchKernelGGL((copy_rows_kernel<VB, kScatter>), rl.grid, dim3(256), 0, stream, d, rl.geom, src, dst);
         else
-            hipLaunchKernelGGL((copy_rows_kernel<VB, kMapPairs>), dim3(grid), dim3(256), 0, stream, d, src, dst);
+            hipLaunchKernelGGL((copy_rows_kernel<VB, kMapPairs>), rl.grid, dim3(256), 0, stream, d, rl.geom, src, dst);
     });
     return accv::check_launch(who);
 }
@@ -415,8 +461,9 @@ int accv_ragged_gather_fill(const void* src, void* dst, const void* indices, con
     if (vb < elem_size) return accv::fail(ACCV_EINVAL, "ragged_gather_fill: data not aligned to its element size");
     RaggedDesc d{indices, nullptr, counts, batch, w_idx, idx_stride, w_src, w_idx, row_bytes / vb, idx_i64, counts_i64,
                  err_counter};
-    const unsigned grid = grid_for(batch * w_idx * d.row_vecs);
-    DISPATCH_VB(vb, hipLaunchKernelGGL((gather_fill_kernel<VB>), dim3(grid), dim3(256), 0, stream, d, src, dst,
+    const RowLaunch rl = row_launch(batch, w_idx, d.row_vecs);
+    if (!rl.ok) return accv::fail(ACCV_EINVAL, "ragged_gather_fill: %lld index slots per sample exceed the grid limit", w_idx);
+    DISPATCH_VB(vb, hipLaunchKernelGGL((gather_fill_kernel<VB>), rl.grid, dim3(256), 0, stream, d, rl.geom, src, dst,
                                        make_pattern<VB>(fill_bits, elem_size)));
     return accv::check_launch("ragged_gather_fill");
 }
@@ -452,8 +499,9 @@ int accv_ragged_insert_const(void* dst, const void* indices, const void* counts,
     int vb = pick_vec(row_bytes, {dst});
     if (vb < elem_size) return accv::fail(ACCV_EINVAL, "ragged_insert_const: data not aligned to its element size");
     RaggedDesc d{indices, nullptr, counts, batch, w_idx, idx_stride, 0, w_dst, row_bytes / vb, idx_i64, counts_i64, err_counter};
-    const unsigned grid = grid_for(batch * w_idx * d.row_vecs);
-    DISPATCH_VB(vb, hipLaunchKernelGGL((insert_const_kernel<VB>), dim3(grid), dim3(256), 0, stream, d, dst,
+    const RowLaunch rl = row_launch(batch, w_idx, d.row_vecs);
+    if (!rl.ok) return accv::fail(ACCV_EINVAL, "ragged_insert_const: %lld index slots per sample exceed the grid limit", w_idx);
+    DISPATCH_VB(vb, hipLaunchKernelGGL((insert_const_kernel<VB>), rl.grid, dim3(256), 0, stream, d, rl.geom, dst,
                                        make_pattern<VB>(elem_bits, elem_size)));
     return accv::check_launch("ragged_insert_const");
 }
@@ -470,9 +518,10 @@ int accv_ragged_pad_fill(void* data, const void* counts, long long batch, long l
     int vb = pick_vec(row_bytes, {data});
     if (vb < elem_size) return accv::fail(ACCV_EINVAL, "ragged_pad_fill: data not aligned to its element size");
     const long long row_vecs = row_bytes / vb;
-    const unsigned grid = grid_for(batch * width * row_vecs);
-    DISPATCH_VB(vb, hipLaunchKernelGGL((pad_fill_kernel<VB>), dim3(grid), dim3(256), 0, stream, data, counts, counts_i64,
-                                       batch, width, row_vecs, make_pattern<VB>(elem_bits, elem_size)));
+    const RowLaunch rl = row_launch(batch, width, row_vecs);
+    if (!rl.ok) return accv::fail(ACCV_EINVAL, "ragged_pad_fill: width %lld exceeds the grid limit", width);
+    DISPATCH_VB(vb, hipLaunchKernelGGL((pad_fill_kernel<VB>), rl.grid, dim3(256), 0, stream, data, counts, counts_i64,
+                                       batch, width, row_vecs, rl.geom, make_pattern<VB>(elem_bits, elem_size)));
     return accv::check_launch("ragged_pad_fill");
 }
 
@@ -489,8 +538,9 @@ int accv_ragged_accumulate(const void* src, void* dst, const void* src_indices_o
     const int pairs = src_indices_or_null != nullptr;
     RaggedDesc d{pairs ? src_indices_or_null : dst_indices, pairs ? dst_indices : nullptr, counts, batch, w_idx, idx_stride,
                  w_src, w_dst, row_elems, idx_i64, counts_i64, err_counter};
-    const unsigned grid = grid_for(batch * w_idx * row_elems);
-#define ACC_CASE(A) case A: hipLaunchKernelGGL((accumulate_rows_kernel<A>), dim3(grid), dim3(256), 0, stream, d, src, dst, pairs); break;
+    const RowLaunch rl = row_launch(batch, w_idx, row_elems);
+    if (!rl.ok) return accv::fail(ACCV_EINVAL, "ragged_accumulate: %lld index slots per sample exceed the grid limit", w_idx);
+#define ACC_CASE(A) case A: hipLaunchKernelGGL((accumulate_rows_kernel<A>), rl.grid, dim3(256), 0, stream, d, rl.geom, src, dst, pairs); break;
     switch (acc_dtype) {
         ACC_CASE(kF32) ACC_CASE(kF64) ACC_CASE(kI32) ACC_CASE(kI64) ACC_CASE(kF16) ACC_CASE(kBF16)
     }
@@ -530,11 +580,12 @@ int accv_ragged_pack(const void* flat, void* padded, const long long* offsets, c
     if (!flat || !padded || !offsets || !sizes) return accv::fail(ACCV_EINVAL, "ragged_pack: null pointer");
     const int vb = pick_vec(row_bytes, {flat, padded});
     const long long row_vecs = row_bytes / vb;
-    const unsigned grid = grid_for(batch * width * row_vecs);
+    const RowLaunch rl = row_launch(batch, width, row_vecs);
+    if (!rl.ok) return accv::fail(ACCV_EINVAL, "ragged_pack: width %lld exceeds the grid limit", width);
     const void* in = unpack ? padded : flat;
     void* out = unpack ? const_cast<void*>(flat) : padded;
-    DISPATCH_VB(vb, hipLaunchKernelGGL((pack_rows_kernel<VB>), dim3(grid), dim3(256), 0, stream, in, out, offsets, sizes,
-                                       batch, width, row_vecs, unpack));
+    DISPATCH_VB(vb, hipLaunchKernelGGL((pack_rows_kernel<VB>), rl.grid, dim3(256), 0, stream, in, out, offsets, sizes,
+                                       batch, width, row_vecs, rl.geom, unpack));
     return accv::check_launch("ragged_pack");
 }
 }

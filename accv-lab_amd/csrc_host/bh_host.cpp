@@ -152,6 +152,9 @@ std::vector<at::Tensor> split_views(const at::Tensor& flat, const std::vector<in
             if (back) std::swap(sz[0], sz[(size_t)back]);
             impl->set_sizes_and_strides(sz, vstrides);
             impl->set_storage_offset(flat.storage_offset() + i * flat.stride(0));
+            // share the base's version counter as a real ATen view does: an in-place write through a sample must be
+            // seen by autograd's "modified in place" check of anything that saved the padded tensor
+            impl->set_version_counter(flat.unsafeGetTensorImpl()->version_counter());
             out.emplace_back(std::move(impl));
             continue;
         }

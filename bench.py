@@ -10,6 +10,13 @@ object lists already resident in HBM.  Prints ONE JSON line on rank 0.
     python bench.py --gpus 1 --steps 500 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+The line is self-certifying: `roofline.kernel` is the dispatch string the library reports for the launches that were
+timed, `roofline.achieved` comes from HIP events on the launch stream inside this run, `roofline.traffic` is only
+quoted from a committed PMC profile of THE SAME kernel instantiation (else null), and the §8(d) work counters, the
+rule-B and in-place rates and the CPU baselines (all cores and one core) are measured in this run.
+The multi-rank control flow (rank layout, per-rank seeds, barrier-bracketed timed region, MAX over ranks) lives in
+accvlab.draw_heatmap.sharding and is exercised on two gloo ranks by tests/test_sharding_gloo.py.
 """
 from __future__ import annotations
 
@@ -29,12 +36,16 @@ import torch  # noqa: E402
 import bench_workloads as wl  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
+# v_exp_f32 issues one wave64 instruction per 8 cycles per SIMD (same guide, "vector-instruction ISSUE cost"):
+# 256 CUs x 4 SIMDs x 64 lanes / 8 cycles x 2.4 GHz
+EXP_PEAK_PER_S = 256 * 4 * 64 / 8 * 2.4e9
 H, W = 1080, 1920
+TRAFFIC_PROFILE = os.path.join("profiles", "r02_traffic.json")
 
 
 def cpu_baseline(centers_l, radii_l, batch):
-    """The CPU oracle (oracle/h1_splat.c, a port of the reference semantics — kind 'port') timed on this host's
-    cores over the same batch: bounded sample = one pass over the full 64-frame batch, OpenMP over frames."""
+    """The CPU oracle (oracle/h1_splat.c, a port of the reference semantics — kind 'port') timed on this host's cores over
+    the same batch (bounded sample), all cores (OpenMP over frames) and ONE core (SURVEY §8d asks for both)."""
     import numpy as np
 
     from oracle import h1 as oracle
@@ -51,13 +62,53 @@ def cpu_baseline(centers_l, radii_l, batch):
     oracle.draw_heatmap_batched(hm[:2], c[:2], r[:2], s[:2], clear=True, threads=min(2, cores))  # page-in / warm
     passes, dt = 0, 0.0
     t0 = time.perf_counter()
-    while passes < 16 and dt * cores < 15.0:      # bounded: ~15-30 s of CPU work (cores x wall)
+    while passes < 16 and dt * cores < 12.0:      # bounded: ~12-24 s of CPU work (cores x wall)
         oracle.draw_heatmap_batched(hm, c, r, s, clear=True, threads=cores)
         passes += 1
         dt = time.perf_counter() - t0
+    # one core: a bounded number of leading frames
+    n1, dt1 = 0, 0.0
+    t0 = time.perf_counter()
+    while n1 < batch and dt1 < 4.0:
+        k = min(4, batch - n1)
+        oracle.draw_heatmap_batched(hm[n1:n1 + k], c[n1:n1 + k], r[n1:n1 + k], s[n1:n1 + k], clear=True, threads=1)
+        n1 += k
+        dt1 = time.perf_counter() - t0
     return {"value": passes * batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{passes} fused clear+draw passes over the full {batch}-frame C1 batch (rule A), "
-                      f"{dt:.2f} s wall = {dt * cores:.0f} core-seconds, OpenMP over frames"}
+                      f"{dt:.2f} s wall = {dt * cores:.0f} core-seconds, OpenMP over frames",
+            "single_thread": {"value": n1 / dt1, "unit": "frames/s", "cores": 1,
+                              "sample": f"first {n1} frames of the same batch, {dt1:.2f} s"}}
+
+
+def work_counters(centers_l, radii_l, tile_w, tile_h):
+    """SURVEY §8(d) work counters from the inputs (numpy, exact): sum of clipped (2r+1)^2 per frame, tiles touched,
+    objects-per-tile histogram, and the number of exp evaluations the tile kernel issues for them."""
+    import numpy as np
+
+    tx, ty = -(-W // tile_w), -(-H // tile_h)
+    area_sum, frames = 0, len(radii_l)
+    hits = np.zeros((frames, ty, tx), dtype=np.int32)
+    touched_px = 0
+    for f, (c, r) in enumerate(zip(centers_l, radii_l)):
+        c, r = c.numpy().astype(np.int64), r.numpy().astype(np.int64)
+        x0, x1 = np.clip(c[:, 0] - r, 0, W), np.clip(c[:, 0] + r + 1, 0, W)   # the reference's clipped box (cuh:64-67)
+        y0, y1 = np.clip(c[:, 1] - r, 0, H), np.clip(c[:, 1] + r + 1, 0, H)
+        ok = (x1 > x0) & (y1 > y0) & (r >= 0)
+        area_sum += int(((x1 - x0) * (y1 - y0))[ok].sum())
+        for a0, a1, b0, b1 in zip(x0[ok] // tile_w, (x1[ok] - 1) // tile_w, y0[ok] // tile_h, (y1[ok] - 1) // tile_h):
+            hits[f, b0:b1 + 1, a0:a1 + 1] += 1
+    touched = hits > 0
+    # pixels of touched tiles (tiles on the bottom edge are clipped to the frame)
+    rows = np.minimum(tile_h, H - np.arange(ty) * tile_h)
+    cols = np.minimum(tile_w, W - np.arange(tx) * tile_w)
+    touched_px = int((touched * rows[None, :, None] * cols[None, None, :]).sum())
+    hist = np.bincount(np.minimum(hits.reshape(-1), 16), minlength=17)
+    return {"tile": [tile_w, tile_h], "clipped_area_sum_per_frame": area_sum / frames,
+            "tiles_total": int(hits.size), "tiles_touched": int(touched.sum()),
+            "tile_hits_total": int(hits.sum()), "objects_per_tile_mean": float(hits.mean()),
+            "objects_per_tile_max": int(hits.max()),
+            "objects_per_tile_histogram_0_to_16plus": hist.tolist(), "touched_pixels": touched_px}
 
 
 def device_env(dev_index):
@@ -115,6 +166,20 @@ def device_env(dev_index):
     return env
 
 
+def committed_traffic(kernel: str):
+    """HBM bytes per launch from the committed PMC profile — only if it was taken on the SAME kernel instantiation as
+    the one timed now (the file names it); otherwise (None, reason)."""
+    path = os.path.join(ROOT, TRAFFIC_PROFILE)
+    try:
+        rec = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return None, f"{TRAFFIC_PROFILE} not present"
+    want = kernel.split(" grid")[0]
+    if rec.get("kernel") != want:
+        return None, f"{TRAFFIC_PROFILE} was taken on {rec.get('kernel')!r}, this run dispatched {want!r}"
+    return rec.get("hbm_bytes_per_launch"), f"{TRAFFIC_PROFILE} (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, commit {rec.get('commit')})"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,11 +188,12 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU")
     ap.add_argument("--rule", default="A", choices=["A", "B"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the rule-B / in-place / zero-fill side measurements")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from accvlab.draw_heatmap import sharding
+
+    rank, local_rank, world = sharding.rank_layout()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     # one process per GPU; ACCV_BENCH_BACKEND=gloo lets several ranks share a GPU to REHEARSE the multi-rank control flow
@@ -136,20 +202,15 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # used only for the barrier and the max-over-ranks of the time
+    dist = sharding.init_process_group(world, backend, dev)   # only the barrier and the max-over-ranks use it
 
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
+    from accvlab import _amd_native as nat
     from accvlab.batching_helpers import combine_data
     from accvlab.draw_heatmap import draw_heatmap_batched
 
     B = args.batch
-    centers_l, radii_l = wl.heatmap_objects(B, H, W, 1, 128, args.rule, seed=42 + rank)
+    seed = sharding.rank_seed(42, rank)
+    centers_l, radii_l = wl.heatmap_objects(B, H, W, 1, 128, args.rule, seed=seed)
     centers = combine_data(centers_l, device=dev)                       # RaggedBatch i32 [B, Nmax, 2]
     radii = combine_data(radii_l, device=dev, other_with_same_sample_sizes=centers)
     n_objects = int(sum(int(r.shape[0]) for r in radii_l))
@@ -158,17 +219,12 @@ def main():
     def step():
         draw_heatmap_batched(hm, centers, radii, 6.0, 1.0, clear=True)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    sync = torch.cuda.synchronize
     for _ in range(args.warmup):
         step()
     # extra untimed pre-warm: the chip needs ~15 ms of back-to-back launches after an idle/sync before kernel times
     # settle (profiles/r01_rocprof: 109 -> 128 -> 97 us); keep the queue full for >= 100 ms before timing
-    torch.cuda.synchronize()
+    sync()
     t_pre = time.perf_counter()
     env = None
     while time.perf_counter() - t_pre < 0.1:
@@ -176,42 +232,71 @@ def main():
             step()
         if env is None and rank == 0 and time.perf_counter() - t_pre > 0.05:
             env = device_env(dev_index)     # sampled under load, outside the timed region
-        torch.cuda.synchronize()
+        sync()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    e0.record()  # same (current) stream the kernel is launched on
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    barrier()
-    t1 = time.perf_counter()
-    wall_ms = (t1 - t0) * 1e3 / args.steps
-    kern_ms = e0.elapsed_time(e1) / args.steps
-    if dist is not None:
-        t = torch.tensor([wall_ms, kern_ms], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall_ms, kern_ms = float(t[0]), float(t[1])
 
-    # secondary, rank 0 only: the reference's exact in-place semantics, and the streaming-write ceiling
+    def timed_step_region():
+        # HIP events on the CURRENT stream = the stream the kernel is launched on; recorded inside the barrier bracket
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
+
+    # exactly K steps between barrier + synchronize brackets; wall clock of this rank, MAX over ranks below
+    wall_ms = sharding.timed_steps(timed_step_region, 1, dist=dist, sync=sync) / args.steps
+    kern_ms = e0.elapsed_time(e1) / args.steps
+    kernel = nat.last_dispatch()
+    red_dev = dev if backend == "nccl" else None
+    wall_ms = sharding.max_over_ranks(wall_ms, device=red_dev)
+    kern_ms = sharding.max_over_ranks(kern_ms, device=red_dev)
+
+    # secondary, rank 0 only: rule B, the reference's exact in-place semantics, and the streaming-write ceiling
     extra = {}
-    if rank == 0:
-        def timed(fn, iters=50):
-            for _ in range(5):
+    if rank == 0 and not args.no_secondary:
+        def timed(fn, iters=50, warm=20):
+            for _ in range(warm):
                 fn()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
+            sync()
             a.record()
             for _ in range(iters):
                 fn()
             b.record()
-            torch.cuda.synchronize()
+            sync()
             return a.elapsed_time(b) / iters
 
+        frame_bytes = H * W * 4
         ms_inplace = timed(lambda: draw_heatmap_batched(hm, centers, radii, 6.0, 1.0))
+        k_inplace = nat.last_dispatch()
         ms_zero = timed(lambda: hm.zero_())
-        extra = {"inplace_frames_per_s": B / ms_inplace * 1e3, "inplace_ms": ms_inplace,
-                 "torch_zero_fill_GBps": hm.numel() * 4 / ms_zero / 1e6}
+        wc_in = work_counters(centers_l, radii_l, 128, 16 if "R=8" in k_inplace else 32)
+        in_bytes = 8 * wc_in["touched_pixels"] + 12 * n_objects + 4 * B       # read + write of touched tiles only
+        extra = {
+            "inplace": {"frames_per_s": B / ms_inplace * 1e3, "ms": ms_inplace, "kernel": k_inplace,
+                        "algorithmic_bytes": in_bytes, "achieved_GBps": in_bytes / ms_inplace / 1e6,
+                        "frac": in_bytes / ms_inplace / 1e6 / HBM_PEAK_GBPS,
+                        "note": "reference semantics (max into the existing map): 8 B per pixel of every touched tile, "
+                                "untouched tiles cost nothing (SURVEY 8d)"},
+            "zero_then_inplace_frames_per_s": B / (ms_inplace + ms_zero) * 1e3,
+            "torch_zero_fill_GBps": hm.numel() * 4 / ms_zero / 1e6, "torch_zero_fill_ms": ms_zero,
+        }
+        other = "B" if args.rule == "A" else "A"
+        cb_l, rb_l = wl.heatmap_objects(B, H, W, 1, 128, other, seed=seed)
+        cb = combine_data(cb_l, device=dev)
+        rbb = combine_data(rb_l, device=dev, other_with_same_sample_sizes=cb)
+        nb = int(sum(int(r.shape[0]) for r in rb_l))
+        ms_b = timed(lambda: draw_heatmap_batched(hm, cb, rbb, 6.0, 1.0, clear=True))
+        k_b = nat.last_dispatch()
+        ms_b_in = timed(lambda: draw_heatmap_batched(hm, cb, rbb, 6.0, 1.0))
+        wc_b = work_counters(cb_l, rb_l, 128, 16)
+        b_bytes = B * frame_bytes + 12 * nb + 4 * B
+        b_in_bytes = 8 * wc_b["touched_pixels"] + 12 * nb + 4 * B
+        extra[f"rule_{other}"] = {
+            "objects": nb, "clear": {"frames_per_s": B / ms_b * 1e3, "ms": ms_b, "kernel": k_b, "algorithmic_bytes": b_bytes,
+                                     "achieved_GBps": b_bytes / ms_b / 1e6, "frac": b_bytes / ms_b / 1e6 / HBM_PEAK_GBPS},
+            "inplace": {"frames_per_s": B / ms_b_in * 1e3, "ms": ms_b_in, "algorithmic_bytes": b_in_bytes,
+                        "achieved_GBps": b_in_bytes / ms_b_in / 1e6},
+            "clipped_area_sum_per_frame": wc_b["clipped_area_sum_per_frame"], "tiles_touched": wc_b["tiles_touched"]}
 
     if rank != 0:
         if dist is not None:
@@ -221,16 +306,17 @@ def main():
 
     alg_bytes = B * H * W * 4 + 12 * n_objects + 4 * B  # H*W*4 + 12*N_i + 4 per frame
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_source = committed_traffic(kernel)
+    tile_h = 32 if "R=16" in kernel else 16
+    wc = work_counters(centers_l, radii_l, 128, tile_h)
+    # exp evaluations of the tile kernel: per (tile, hit) one row-factor table entry per tile row + 4 column factors per lane
+    exps = wc["tile_hits_total"] * (tile_h + 256)
+    wc["exp_evaluations_per_launch"] = exps
+    wc["transcendental_ceiling"] = {"peak_exp_per_s": EXP_PEAK_PER_S, "min_ms_per_launch": exps / EXP_PEAK_PER_S * 1e3,
+                                    "fraction_of_kernel_time": exps / EXP_PEAK_PER_S * 1e3 / kern_ms}
     out = {
         "metric": "heatmap frames/sec (1920x1080 fp32, ragged N_obj in [1,128], fused clear+draw)",
-        "value": world * B / (wall_ms * 1e-3),
+        "value": sharding.job_throughput(B, world, wall_ms),
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -243,10 +329,12 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"configs[1]: draw_heatmap_batched 1920x1080, batch {B}/GPU, ragged N_obj in [1,128] "
                                f"via batching_helpers.combine_data, radius rule {args.rule}, factor 6, k 1, fp32",
-                   "frames_per_gpu": B, "objects_per_gpu": n_objects, "parallelism": f"frame-sharded x{world}"},
+                   "frames_per_gpu": B, "objects_per_gpu": n_objects, "parallelism": f"frame-sharded x{world}",
+                   "seed": seed},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": "splat_kernel<4, 16, true, 0, 1> (PX=4, R=16: 128x32 tile, fused clear, plain stores, 1 wave/WG)", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": kernel, "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
+        "work": wc,
         "secondary": extra,
         "device": env or {},
     }

@@ -41,8 +41,15 @@ extern "C" {
 #define ACCV_HM_GROUP_BOXES_GIVEN 16u /* accv_draw_points_multiscale_f32 only: `workspace` already holds the group boxes
                                          (written by accv_polyline_sample_boxes); skip the box launch */
 
+#define ACCV_HM_TILE_ROWS_16 32u /* hint: 128 x 32 pixel tiles (default only for fused-clear launches above 128 MB) */
+#define ACCV_HM_TILE_ROWS_8 64u  /* hint: 128 x 16 pixel tiles (default for everything else).  Same results either way. */
+
 const char* accv_last_error(void);
 int accv_version(void);
+/* Which kernel instantiation and launch geometry the LAST draw_heatmap entry point called on this thread selected
+ * (thread-local, e.g. "splat_kernel<PX=4,R=16,CLEAR=1,SM=0> grid(15,34,64) block(64)"); "" before the first call.
+ * For benchmarks and profiles: the name a rocprofv3 kernel trace shows for that launch starts with the same text. */
+const char* accv_draw_heatmap_last_dispatch(void);
 
 /* ------------------------------------------------------------------------------------------------ H1
  * Gaussian heat-map rasteriser.

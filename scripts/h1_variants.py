@@ -24,8 +24,10 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--warm", type=int, default=300, help="untimed launches of a variant before its timed ones")
-    ap.add_argument("--knobs", default="hm_wpg=1,4;hm_nt=0,4",
-                    help="knobs understood by libaccv_hip: hm_wpg=1|4, hm_rows=8|16, hm_nt=0|1|2|4")
+    ap.add_argument("--knobs", default="",
+                    help="knobs of the A/B build (make -C accv-lab_amd/csrc tune; run with "
+                         "ACCV_HIP_LIB=accv-lab_amd/accvlab/_amd_native/libaccv_hip_tune.so): hm_wpg=1|4, hm_rows=8|16, "
+                         "hm_nt=0|1|2|4, e.g. 'hm_wpg=1,4;hm_nt=0,4'.  Empty: the shipped dispatch only")
     ap.add_argument("--empty", action="store_true", help="no objects: isolates the store pattern")
     ap.add_argument("--nmin", type=int, default=1, help="minimum objects per frame (128 = densest case)")
     ap.add_argument("--alt-lib", default=None,
@@ -44,10 +46,13 @@ def main():
     hm = torch.zeros((B, H, W), device=dev)
     nbytes = B * H * W * 4
     knobs = []
-    for part in args.knobs.split(";"):
+    for part in [p for p in args.knobs.split(";") if p]:
         k, vals = part.split("=")
         knobs.append([(k, int(v)) for v in vals.split(",")])
-    variants = list(itertools.product(*knobs))
+    variants = list(itertools.product(*knobs)) if knobs else [()]
+    has_knobs = hasattr(nat.ctypes_lib(), "accv_tune_set")
+    if knobs and not has_knobs:
+        raise SystemExit("--knobs needs the A/B build: make -C accv-lab_amd/csrc tune && ACCV_HIP_LIB=.../libaccv_hip_tune.so")
     lib = nat.lib()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -93,7 +98,8 @@ def main():
                 res.setdefault(var + (mode,), []).append(t)
         if alt is not None:  # both builds through the bare C-ABI, default knobs
             for k, v in (("hm_wpg", 1), ("hm_rows", -1), ("hm_nt", -1)):
-                nat.tune_set(k, v)
+                if has_knobs:
+                    nat.tune_set(k, v)
             for mode in ("clear", "inplace"):
                 for name, handle in (("shipped", lib), ("alt", alt)):
                     t = timed(lambda: draw_with(handle, mode == "clear"))

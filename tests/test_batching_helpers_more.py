@@ -214,3 +214,23 @@ def test_error_paths_of_the_index_ops(dev):
         batched_indexing_write(torch.zeros(2, 2, 4, device=dev), i64, d)   # inconsistent trailing dims
     m = get_mask_from_indices(5, i64)
     assert m.shape == (2, 5) and m[:, 0].all() and not m[:, 1:].any()
+
+
+@pytest.mark.parametrize("dev", GPU_ONLY)
+def test_no_grad_results_do_not_require_grad(dev):
+    # under torch.no_grad() Function.apply returns tensors that do not require grad even when an input
+    # does (a parameter); the no-autograd fast path has to behave the same
+    x = torch.rand(2, 5, 3, device=dev, requires_grad=True)
+    idx = RaggedBatch(torch.tensor([[0, 2, 4], [1, 3, 0]], device=dev), sample_sizes=torch.tensor([3, 2], device=dev))
+    into = torch.zeros(2, 6, 3, device=dev, requires_grad=True)
+    with torch.no_grad():
+        a = batched_indexing_access(x, idx, 0.5)
+        b = batched_inverse_indexing_access(x[:, :3], idx, 6, 0.0)
+        c = batched_indexing_write(x[:, :3], idx, into)
+        d = batched_index_mapping(x, idx, idx, into)
+    for t in (a.tensor, b, c, d):
+        assert t.requires_grad is False and t.grad_fn is None
+        t.add_(1.0)                                   # in-place edits of such results are legal
+    # with grad mode on the same calls are differentiable
+    a = batched_indexing_access(x, idx, 0.5)
+    assert a.tensor.requires_grad and a.tensor.grad_fn is not None

@@ -149,3 +149,20 @@ def test_gpu_split_views_alias_the_batch():
     fast, slow = _both(lambda: rb.split())
     for a, b in zip(fast, slow):
         assert a.shape == b.shape and a.data_ptr() == b.data_ptr() and torch.equal(a, b)
+
+
+def test_split_views_share_the_version_counter_of_the_batch():
+    # a sample returned by split() is a view of the padded tensor — an in-place write through it must bump
+    # the batch tensor's version so autograd's "modified in place" check of anything that saved it still fires
+    rb = RaggedBatch(torch.arange(24.0).reshape(3, 4, 2).clone(), sample_sizes=torch.tensor([4, 2, 1]))
+    before = rb.tensor._version
+    parts = rb.split()
+    parts[1].mul_(2.0)
+    assert rb.tensor._version > before
+    # and the check itself: w * tensor saves the tensor; editing a split view afterwards must make backward fail
+    w = torch.ones(3, 4, 2, requires_grad=True)
+    rb2 = RaggedBatch(torch.rand(3, 4, 2), sample_sizes=torch.tensor([4, 2, 1]))
+    y = (w * rb2.tensor).sum()
+    rb2.split()[0].zero_()
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        y.backward()

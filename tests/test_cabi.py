@@ -41,15 +41,22 @@ def test_version_and_error_string():
     assert isinstance(lib.accv_last_error(), (bytes, type(None)))
 
 
-def test_argument_validation_without_gpu():
+@pytest.mark.parametrize("path", ["trampoline", "ctypes"])
+def test_argument_validation_without_gpu(path):
+    """the same entry points through both host bindings: the METH_FASTCALL trampoline (accvlab/_amd_native/_fastcall,
+    what the operators use) and plain ctypes"""
     from accvlab import _amd_native as nat
 
-    lib = nat.lib()
+    lib = nat.lib() if path == "trampoline" else nat.ctypes_lib()
+    if path == "trampoline":
+        assert nat._fastcall is not None, "build the host extensions (make -C accv-lab_amd/csrc_host)"
+        import functools
+        assert isinstance(lib.accv_ragged_gather, functools.partial)          # int-only signature -> call_ints
     # negative extents -> ACCV_EINVAL before anything touches the device
     assert lib.accv_draw_heatmap_batched_f32(None, 1, 0, -1, 4, None, None, None, None, 0, 6.0, 1.0, 0, None) == -1
     assert b"negative" in lib.accv_last_error()
     # labels without classes
-    dummy = ctypes.c_void_p(16)
+    dummy = 16 if path == "trampoline" else ctypes.c_void_p(16)
     assert lib.accv_draw_heatmap_batched_f32(dummy, 1, 0, 4, 4, dummy, dummy, dummy, dummy, 1, 6.0, 1.0, 0, None) == -1
     # workspace too small
     assert lib.accv_draw_heatmap_flat_f32(dummy, 2, 4, 4, dummy, dummy, dummy, 3, 6.0, 1.0, 0, dummy, 8, None) == -3
@@ -57,5 +64,9 @@ def test_argument_validation_without_gpu():
     # empty problems succeed without touching the device
     assert lib.accv_draw_heatmap_batched_f32(None, 0, 0, 4, 4, None, None, None, None, 0, 6.0, 1.0, 0, None) == 0
     assert lib.accv_fill_f32(None, 0, 0.0, None) == 0
+    # integer-class arguments: negative values, None pointers and the error string survive the trampoline
+    assert lib.accv_ragged_gather(dummy, dummy, dummy, dummy, -1, 4, 4, 4, 16, 0, 0, None, None) == -1
+    assert b"invalid extents" in lib.accv_last_error()
+    assert lib.accv_ragged_gather(None, None, None, None, 0, 4, 4, 4, 16, 0, 0, None, None) == 0
     with pytest.raises(nat.AccvNativeError):
         nat.check(-1, "unit test")

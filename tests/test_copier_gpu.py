@@ -200,3 +200,43 @@ def test_many_small_gpu_tensors_to_cpu_are_coalesced(pinned):
     assert len(set(ptrs)) == 1
     if pinned:
         assert all(t.is_pinned() for t in out["x"][:300])
+
+
+@pytest.mark.parametrize("background", [True, False])
+def test_failed_copy_returns_its_staging_blocks(background, monkeypatch):
+    """when the worker raises after the first chunk was staged and enqueued, the handle must still wait for
+    the transfers in flight and hand the pinned arena blocks back (they used to leak for the life of the process)."""
+    mtc = _mtc()
+    from accvlab import _amd_native as nat
+    from accvlab.multi_tensor_copier import copier
+
+    lib = nat.lib()
+    data = [torch.rand(1000) for _ in range(64)]
+    mtc.start_copy(data, DEV).get()                         # warm the arena: the size class now sits in the free list
+    torch.cuda.synchronize()
+    lib.accv_pinned_trim()
+    assert lib.accv_pinned_total_bytes() == 0               # nothing is live, nothing is cached
+    real_check = nat.check
+
+    def failing_check(status, what=""):
+        real_check(status, what)
+        if what == "mtc_stage_h2d":                         # the staging + transfer of the chunk HAS been enqueued
+            raise RuntimeError("injected failure after the first chunk")
+
+    monkeypatch.setattr(copier._nat, "check", failing_check)
+    if background:
+        h = mtc.start_copy(data, DEV, use_background_thread=True)
+        with pytest.raises(RuntimeError, match="injected failure"):
+            h.get()
+        with pytest.raises(RuntimeError, match="injected failure"):
+            h.ready()                                       # keeps raising, as the reference's handle does
+    else:
+        with pytest.raises(RuntimeError, match="injected failure"):
+            mtc.start_copy(data, DEV, use_background_thread=False)
+    monkeypatch.setattr(copier._nat, "check", real_check)
+    torch.cuda.synchronize()
+    held = lib.accv_pinned_total_bytes()
+    lib.accv_pinned_trim()                                  # frees only blocks that were RELEASED back to the arena
+    assert held > 0 and lib.accv_pinned_total_bytes() == 0, "a staging block of the failed copy is still marked live"
+    out = mtc.start_copy(data, DEV).get()                   # and the copier still works
+    assert all(torch.equal(a, b.cpu()) for a, b in zip(data, out))

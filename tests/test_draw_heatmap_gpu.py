@@ -22,22 +22,26 @@ def rb(t, sizes):
     return SimpleNamespace(tensor=t, sample_sizes=sizes)
 
 
-_VARIANTS = {"shipped": {}, "rows16": {"hm_rows": 16}, "rows8-wt-nt": {"hm_rows": 8, "hm_nt": 4}, "wpg4": {"hm_wpg": 4},
-             "small-splat": {"hm_small": 1}}
-_DEFAULTS = {"hm_rows": -1, "hm_nt": -1, "hm_wpg": 1, "hm_small": -1}
+_VARIANTS = {"shipped": 0, "rows16": "HM_TILE_ROWS_16", "rows16-wt-nt": ("HM_TILE_ROWS_16", "HM_WRITE_THROUGH"),
+             "rows8-wt-nt": ("HM_TILE_ROWS_8", "HM_WRITE_THROUGH"), "small-splat": "HM_SMALL_RADII"}
 
 
 @pytest.fixture(autouse=True, params=list(_VARIANTS), ids=list(_VARIANTS))
 def kernel_variant(request):
-    """every test of this module runs against the shipped splat-kernel instantiation and the alternative ones that
-    the tune knobs can select (tile rows, waves per workgroup, the box-walking small-splat kernel)"""
+    """every test of this module runs against the default dispatch and against every other splat-kernel instantiation
+    the shipped library holds, selected through the PUBLIC hint flags (tile rows, write-through stores, the box-walking
+    small-splat kernel); the dispatch actually taken is checked"""
     from accvlab import _amd_native as nat
+    from accvlab.draw_heatmap import ops
 
-    for k, v in _VARIANTS[request.param].items():
-        nat.tune_set(k, v)
+    names = _VARIANTS[request.param]
+    names = () if names == 0 else ((names,) if isinstance(names, str) else names)
+    flags = 0
+    for n in names:
+        flags |= getattr(nat, n)
+    ops._FORCED_FLAGS = flags
     yield request.param
-    for k, v in _DEFAULTS.items():
-        nat.tune_set(k, v)
+    ops._FORCED_FLAGS = 0
 
 
 def _dh():
@@ -427,3 +431,29 @@ def test_batched_op_is_graph_capturable():
     ref2 = np.zeros((B, H, W), dtype=np.float32)
     oracle.draw_heatmap_batched(ref2, c.tensor.cpu().numpy(), r.tensor.cpu().numpy(), s2.numpy(), clear=True)
     _close(hm, ref2, "graph replay with new inputs")
+
+
+def test_dispatch_string_follows_the_public_hints(kernel_variant):
+    """accv_draw_heatmap_last_dispatch reports the instantiation that ran (bench.py derives roofline.kernel from it)"""
+    from accvlab import _amd_native as nat
+
+    _, draw_heatmap_batched = _dh()
+    hm = torch.zeros(2, 64, 256, device=DEV)
+    c = torch.tensor([[[10, 10]], [[100, 30]]], dtype=torch.int32, device=DEV)
+    r = torch.tensor([[3], [5]], dtype=torch.int32, device=DEV)
+    n = torch.tensor([1, 1], device=DEV)
+    draw_heatmap_batched(hm, rb(c, n), rb(r, n), clear=True)
+    s = nat.last_dispatch()
+    if kernel_variant == "small-splat":
+        assert s.startswith("splat_small_kernel<")
+    else:
+        assert s.startswith("splat_kernel<PX=4,")
+        assert ("R=16" in s) == kernel_variant.startswith("rows16")
+    assert ("SM=4" in s) == kernel_variant.endswith("wt-nt")
+    assert "CLEAR=1" in s and "block(64)" in s
+    # a map whose width is not a multiple of 4 takes the scalar instantiation whatever the hints say
+    odd = torch.zeros(1, 8, 30, device=DEV)
+    draw_heatmap_batched(odd, rb(c[:1], n[:1]), rb(r[:1], n[:1]))
+    assert nat.last_dispatch().startswith("splat_kernel<PX=1,R=8,CLEAR=0,SM=0>")
+    with pytest.raises(RuntimeError):
+        draw_heatmap_batched(hm, rb(c, n), rb(r, n), tile_rows=12)

