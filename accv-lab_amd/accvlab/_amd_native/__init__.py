@@ -22,6 +22,7 @@ HM_WRITE_THROUGH = 8
 HM_GROUP_BOXES_GIVEN = 16
 HM_TILE_ROWS_16 = 32
 HM_TILE_ROWS_8 = 64
+HM_PLAIN_STORES = 128
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -56,6 +57,9 @@ SIGNATURES = {
     "accv_ragged_accumulate": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _i, _i, _vp, _vp]),
     "accv_ragged_mask_to_indices": (_i, [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp]),
     "accv_ragged_pack": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _i, _vp]),
+    "accv_matched_pair_reduce_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _f, _i, _i, _vp, _vp]),
+    "accv_matched_pair_reduce_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _f, _i, _i,
+                                              _vp, _vp, _vp, _vp]),
     # H3 multi-tensor copier
     "accv_mtc_plan": (_i, [_ll, _vp, _vp, _vp, _ll, _ll, _vp, _vp, _vp, _vp]),
     "accv_pinned_acquire": (_vp, [_sz]),
@@ -65,6 +69,9 @@ SIGNATURES = {
     "accv_mtc_worker_count": (_i, []),
     "accv_mtc_pack_host": (_i, [_ll, _vp, _vp, _vp, _vp, _ll]),
     "accv_mtc_stage_h2d": (_i, [_ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _i]),
+    "accv_mtc_stage_h2d_async": (_i, [_ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "accv_mtc_async_wait": (_i, [_ll]),
+    "accv_mtc_async_poll": (_i, [_ll]),
     "accv_mtc_coalesce": (_i, [_vp, _ll, _vp, _i, _vp]),
     "accv_memcpy_async": (_i, [_vp, _vp, _sz, _i, _vp]),
     # lane_helpers
@@ -88,6 +95,9 @@ if os.environ.get("ACCV_NO_FASTCALL") == "1":
     _fastcall = None
 
 _INT_CLASS = (_vp, _i, _u, _sz, _i64, _ll, _u64)
+# entry points that BLOCK (wait for a native job, run a long host memcpy): they stay on ctypes, which drops the
+# interpreter lock for the duration of the call — the trampoline keeps it
+_BLOCKING = {"accv_mtc_async_wait", "accv_mtc_stage_h2d", "accv_mtc_pack_host"}
 
 
 def _fast_entry(fn, res, args):
@@ -117,7 +127,7 @@ class _Lib:
     def __getattr__(self, name):
         fn = getattr(self._ctypes, name)
         sig = SIGNATURES.get(name) or _PRIVATE.get(name)
-        fast = _fast_entry(fn, *sig) if sig else None
+        fast = _fast_entry(fn, *sig) if sig and name not in _BLOCKING else None
         fn = fast or fn
         setattr(self, name, fn)       # cached: __getattr__ is not consulted again
         return fn

@@ -32,6 +32,8 @@ from .batched_processing_py import (
     combine_data,
 )
 
+from .fused import matched_pair_loss_sum  # (extension) gathers + per-object loss + masked sum in one launch
+
 __version__ = "0.1.0"
 
 __all__ = [
@@ -50,6 +52,7 @@ __all__ = [
     "get_compact_lists",
     "get_indices_from_mask",
     "get_mask_from_indices",
+    "matched_pair_loss_sum",
     "squeeze_except_batch_and_sample",
     "sum_over_targets",
 ]

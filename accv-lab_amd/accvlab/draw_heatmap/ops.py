@@ -25,7 +25,7 @@ def _hint_flags(clear: bool, small_radii: bool, write_through: bool, tile_rows) 
     if tile_rows not in (None, 8, 16):
         raise RuntimeError("tile_rows must be None, 8 or 16")
     return (_nat.HM_CLEAR if clear else 0) | (_nat.HM_SMALL_RADII if small_radii else 0) | \
-        (_nat.HM_WRITE_THROUGH if write_through else 0) | \
+        (0 if write_through is None else _nat.HM_WRITE_THROUGH if write_through else _nat.HM_PLAIN_STORES) | \
         (_nat.HM_TILE_ROWS_16 if tile_rows == 16 else _nat.HM_TILE_ROWS_8 if tile_rows == 8 else 0) | _FORCED_FLAGS
 
 
@@ -64,7 +64,7 @@ def draw_heatmap(
     *,
     clear: bool = False,
     small_radii: bool = False,
-    write_through: bool = False,
+    write_through: Optional[bool] = None,
     tile_rows: Optional[int] = None,
 ) -> None:
     """Draw N Gaussians into ``heatmaps[P,H,W]`` (fp32, in place, element-wise max).
@@ -79,8 +79,10 @@ def draw_heatmap(
         clear: (extension) overwrite the map with max(0, splats) instead of max-ing into its content.
         small_radii: (extension) performance hint — the radii are a few pixels (key points, lane samples; boxes up to
             ~15x15): use the kernel that walks each object's box instead of updating whole tiles.  Same results.
-        write_through: (extension) performance hint — write-through non-temporal stores; pays a few per cent for dense
-            launches that rewrite hundreds of MB, costs up to 27 % for sparse in-place ones (default off).  Same results.
+        write_through: (extension) performance hint — True: write-through non-temporal stores everywhere (pays a few per
+            cent for dense launches that rewrite hundreds of MB, costs up to 27 % for sparse in-place ones); False: plain
+            stores everywhere; None (default): plain for fused-clear launches, and for in-place launches the kernel
+            decides per plane from the density of its objects.  Same results.
 
     Reference: draw_heatmap.cpp:132-134 -> draw_heatmap_launcher (draw_heatmap_cuda.cu:62-89).
     """
@@ -130,7 +132,7 @@ def draw_heatmap_batched(
     *,
     clear: bool = False,
     small_radii: bool = False,
-    write_through: bool = False,
+    write_through: Optional[bool] = None,
     tile_rows: Optional[int] = None,
 ) -> None:
     """Draw a ragged batch of Gaussians (in place, element-wise max).

@@ -41,7 +41,7 @@ except ImportError:  # pragma: no cover - exercised when the host extension has 
     _host = None
 
 PACK_MAX_BYTES_PER_TENSOR = 256 * 1024  # multi_tensor_copier.cpp:483
-R_REUSE, R_H2D_PACK, R_H2D_SINGLE, R_D2H_SMALL, R_D2H_OTHER, R_D2D, R_OTHER = range(7)
+R_REUSE, R_H2D_PACK, R_H2D_SINGLE, R_D2H_SMALL, R_D2H_OTHER, R_D2D, R_OTHER, R_D2D_SMALL = range(8)
 
 _pool_lock = threading.Lock()
 _pool: Optional[ThreadPoolExecutor] = None
@@ -129,7 +129,7 @@ class _PyLeafSet:
             elif t.device.type == "cuda" and dev.type == "cpu":
                 route[i] = R_D2H_SMALL if (pack and small) else R_D2H_OTHER
             elif t.device.type == "cuda" and dev.type == "cuda":
-                route[i] = R_D2D
+                route[i] = R_D2D_SMALL if (pack and small) else R_D2D
             else:
                 route[i] = R_OTHER
         return route, nbytes, esize, ptr, didx
@@ -193,6 +193,9 @@ class _Job:
         self.source_events = {}
         self.released = False
         self.packed = None               # PackedBatch whose buffer still has to travel (host->GPU)
+        self.ticket = None               # native orchestration job (accv_mtc_stage_h2d_async) still to be waited for
+        self.pending_views = None        # arguments of tree.make_packed_views, built by the consumer while the job runs
+        self.side = None                 # side stream the native job enqueues on
 
     def release_staging(self):
         if not self.released:
@@ -201,6 +204,10 @@ class _Job:
             for p in self.staging:
                 lib.accv_pinned_release(p)
             self.staging = []
+
+
+def nbytes_all(job: _Job) -> np.ndarray:
+    return job.meta[1]
 
 
 def _plan(lib, job: _Job, nbytes: np.ndarray, esize: np.ndarray):
@@ -215,6 +222,77 @@ def _plan(lib, job: _Job, nbytes: np.ndarray, esize: np.ndarray):
     _nat.check(lib.accv_mtc_plan(m, nbytes.ctypes.data, esize.ctypes.data, cand.ctypes.data, job.min_align, job.max_chunk,
                                  off.ctypes.data, chk.ctypes.data, csz.ctypes.data, ctypes.addressof(nck)), "mtc_plan")
     return off, chk, csz, int(nck.value), nbytes
+
+
+def _prepare_packed_h2d(job: _Job, lib, packable: np.ndarray, side):
+    """Pack plan, GPU chunks (allocated on the caller's stream), pinned staging blocks and the stream ordering for the
+    packable host leaves; returns the argument lists of the staging call and of make_packed_views, or None when the
+    plan packs nothing (fewer than two candidates)."""
+    dev = job.device
+    route, nbytes, esize, ptr, didx = job.meta
+    off, chk, csz, n_chunks, pbytes = _plan(lib, job, nbytes[packable], esize[packable])
+    if n_chunks <= 0:
+        return None
+    m = len(packable)
+    align = 16
+    while align < job.min_align:
+        align <<= 1                    # packed_buffer_alignment_bytes, multi_tensor_copier.cpp:399-404
+    order = np.argsort(chk, kind="stable").astype(np.int64)
+    begin = np.searchsorted(chk[order], np.arange(n_chunks + 1)).astype(np.int64)
+    src = np.ascontiguousarray(ptr[packable], dtype=np.uint64)
+    stage_ptrs = np.empty(n_chunks, dtype=np.uint64)
+    dev_ptrs = np.empty(n_chunks, dtype=np.uint64)
+    bases = np.empty(n_chunks, dtype=np.int64)
+    chunks = []
+    with torch.cuda.stream(job.caller_stream):
+        for c in range(n_chunks):
+            size = int(csz[c])
+            g = torch.empty(size + align + 15, dtype=torch.uint8, device=dev)
+            bases[c] = (-g.data_ptr()) % align
+            chunks.append(g)
+            dev_ptrs[c] = g.data_ptr() + int(bases[c])
+            if job.pinned:
+                p = lib.accv_pinned_acquire(size)
+                if not p:
+                    _nat.check(-4, "pinned arena")
+                job.staging.append(p)
+                stage_ptrs[c] = p
+            else:
+                buf = torch.empty(size, dtype=torch.uint8)
+                job.keep.append(buf)
+                stage_ptrs[c] = buf.data_ptr()
+        ready = torch.cuda.Event()
+        ready.record(job.caller_stream)
+    side.wait_event(ready)            # after the caller's work AND after the allocation point
+    job.keep.append(chunks)
+    return {"stage_args": (m, src.ctypes.data, pbytes.ctypes.data, off.ctypes.data, order.ctypes.data, n_chunks,
+                           begin.ctypes.data, stage_ptrs.ctypes.data, dev_ptrs.ctypes.data, csz.ctypes.data),
+            "arrays": (src, pbytes, off, order, begin, stage_ptrs, dev_ptrs, csz),     # keep the buffers alive
+            "views": (packable, chk, off, chunks, bases)}
+
+
+def _start_native_h2d(job: _Job) -> bool:
+    """Background mode without a Python worker: when every leaf is either reused as it is or a packable host tensor
+    (the common case — a batch of small CPU tensors), the caller thread plans and allocates, a NATIVE library thread
+    stages and enqueues (accv_mtc_stage_h2d_async: no interpreter lock anywhere in the work), and the consumer builds the
+    views while that thread runs.  Returns False when the job needs the general python orchestration."""
+    route = job.meta[0]
+    if job.device.type != "cuda" or job.packed is not None:
+        return False
+    packable = np.nonzero(route == R_H2D_PACK)[0].astype(np.int64)
+    if len(packable) < 2 or int(np.count_nonzero((route != R_REUSE) & (route != R_H2D_PACK))) > 0:
+        return False
+    lib = _nat.lib()
+    side = _side_stream(job.device)
+    with torch.cuda.device(job.device):
+        prep = _prepare_packed_h2d(job, lib, packable, side)
+        if prep is None:
+            return False
+        ticket = ctypes.c_longlong(0)
+        _nat.check(lib.accv_mtc_stage_h2d_async(*prep["stage_args"], side.cuda_stream, 0, job.device.index,
+                                                ctypes.addressof(ticket)), "mtc_stage_h2d_async")
+    job.ticket, job.pending_views, job.side = int(ticket.value), prep["views"], side
+    return True
 
 
 def _run(job: _Job) -> None:
@@ -235,49 +313,17 @@ def _run(job: _Job) -> None:
         packable = np.nonzero(route == R_H2D_PACK)[0].astype(np.int64)
         single = np.nonzero(route == R_H2D_SINGLE)[0].tolist()
         d2d = np.nonzero(route == R_D2D)[0].tolist()
+        d2d_small = np.nonzero(route == R_D2D_SMALL)[0].astype(np.int64)
+        for src_index in np.unique(didx[d2d_small]).tolist() if len(d2d_small) else []:
+            group = d2d_small[didx[d2d_small] == src_index]
+            if not (len(group) >= 2 and _coalesced_d2d(job, lib, group, int(src_index), side)):
+                d2d = sorted(d2d + group.tolist())
         with torch.cuda.device(dev):
-            n_chunks = 0
-            if len(packable) >= 2:
-                off, chk, csz, n_chunks, pbytes = _plan(lib, job, nbytes[packable], esize[packable])
-            if n_chunks > 0:
-                m = len(packable)
-                align = 16
-                while align < job.min_align:
-                    align <<= 1                    # packed_buffer_alignment_bytes, multi_tensor_copier.cpp:399-404
-                order = np.argsort(chk, kind="stable").astype(np.int64)
-                begin = np.searchsorted(chk[order], np.arange(n_chunks + 1)).astype(np.int64)
-                src = np.ascontiguousarray(ptr[packable], dtype=np.uint64)
-                stage_ptrs = np.empty(n_chunks, dtype=np.uint64)
-                dev_ptrs = np.empty(n_chunks, dtype=np.uint64)
-                bases = np.empty(n_chunks, dtype=np.int64)
-                chunks = []
-                with torch.cuda.stream(job.caller_stream):
-                    for c in range(n_chunks):
-                        size = int(csz[c])
-                        g = torch.empty(size + align + 15, dtype=torch.uint8, device=dev)
-                        bases[c] = (-g.data_ptr()) % align
-                        chunks.append(g)
-                        dev_ptrs[c] = g.data_ptr() + int(bases[c])
-                        if job.pinned:
-                            p = lib.accv_pinned_acquire(size)
-                            if not p:
-                                _nat.check(-4, "pinned arena")
-                            job.staging.append(p)
-                            stage_ptrs[c] = p
-                        else:
-                            buf = torch.empty(size, dtype=torch.uint8)
-                            job.keep.append(buf)
-                            stage_ptrs[c] = buf.data_ptr()
-                    ready = torch.cuda.Event()
-                    ready.record(job.caller_stream)
-                side.wait_event(ready)            # after the caller's work AND after the allocation point
-                _nat.check(lib.accv_mtc_stage_h2d(m, src.ctypes.data, pbytes.ctypes.data, off.ctypes.data,
-                                                  order.ctypes.data, n_chunks, begin.ctypes.data, stage_ptrs.ctypes.data,
-                                                  dev_ptrs.ctypes.data, csz.ctypes.data, side.cuda_stream, 0),
-                           "mtc_stage_h2d")
+            prep = _prepare_packed_h2d(job, lib, packable, side) if len(packable) >= 2 else None
+            if prep is not None:
+                _nat.check(lib.accv_mtc_stage_h2d(*prep["stage_args"], side.cuda_stream, 0), "mtc_stage_h2d")
                 # typed views into the chunk storage (enqueue_packed_transfer, multi_tensor_copier.cpp:712-729)
-                tree.make_packed_views(packable, chk, off, chunks, bases)
-                job.keep.append(chunks)
+                tree.make_packed_views(*prep["views"])
             else:
                 single = sorted(single + packable.tolist())
             # ---- everything else that targets the GPU goes through torch on the side stream
@@ -365,6 +411,66 @@ def _enqueue_packed_batch(job: _Job, lib, side) -> None:
     job.keep.append(g)
 
 
+def _item_table_to_device(job: _Job, lib, table: np.ndarray, sdev: torch.device, stream) -> torch.Tensor:
+    """{pointer, offset, bytes} table of a coalescing launch -> device memory through a pinned arena block and ONE
+    asynchronous copy on `stream` (a pageable .to(device) would block the host and serialise with the stream)."""
+    tbytes = int(table.nbytes)
+    block = lib.accv_pinned_acquire(tbytes)
+    if not block:
+        _nat.check(-4, "pinned arena")
+    job.staging.append(block)                      # goes back to the arena once the job's events have completed
+    ctypes.memmove(block, table.ctypes.data, tbytes)
+    items = torch.empty(tbytes, dtype=torch.uint8, device=sdev)
+    _nat.check(lib.accv_memcpy_async(items.data_ptr(), block, tbytes, 1, stream.cuda_stream), "memcpy_async")
+    return items
+
+
+def _coalesced_d2d(job: _Job, lib, group: np.ndarray, src_index: int, side_dst) -> bool:
+    """Many small tensors of GPU `src_index` -> ONE gather kernel there (accv_mtc_coalesce) -> ONE device-to-device copy
+    -> typed views of one storage on the target GPU (the reference copies every tensor on its own,
+    multi_tensor_copier.cpp:775-820)."""
+    route, nbytes, esize, ptr, _ = job.meta
+    off, chk, csz, n_chunks, gbytes = _plan(lib, job, nbytes[group], esize[group])
+    if n_chunks == 0:
+        return False
+    sdev, ddev = torch.device("cuda", src_index), job.device
+    side_src = _side_stream(sdev)
+    ptrs = np.ascontiguousarray(ptr[group], dtype=np.uint64)
+    chunks, bases = [], np.zeros(n_chunks, dtype=np.int64)
+    with torch.cuda.device(sdev):
+        side_src.wait_event(job.source_events[src_index])
+        gathered = []
+        with torch.cuda.stream(side_src):
+            for c in range(n_chunks):
+                sel = np.nonzero(chk == c)[0]
+                table = np.empty((len(sel), 3), dtype=np.int64)
+                table[:, 0] = ptrs[sel].view(np.int64)
+                table[:, 1] = off[sel]
+                table[:, 2] = gbytes[sel]
+                items = _item_table_to_device(job, lib, table, sdev, side_src)
+                packed = torch.empty(int(csz[c]) + 16, dtype=torch.uint8, device=sdev)
+                _nat.check(lib.accv_mtc_coalesce(items.data_ptr(), len(sel), packed.data_ptr(), 0, side_src.cuda_stream),
+                           "mtc_coalesce")
+                gathered.append(packed)
+                job.keep.append((items, packed))
+        src_done = torch.cuda.Event()
+        src_done.record(side_src)
+    with torch.cuda.device(ddev):
+        with torch.cuda.stream(job.caller_stream):
+            for c in range(n_chunks):
+                chunks.append(torch.empty((int(csz[c]) + 31) // 16 * 16, dtype=torch.uint8, device=ddev))
+            ready = torch.cuda.Event()
+            ready.record(job.caller_stream)
+        side_dst.wait_event(ready)
+        side_dst.wait_event(src_done)
+        with torch.cuda.stream(side_dst):
+            for c in range(n_chunks):
+                chunks[c][:int(csz[c]) + 16].copy_(gathered[c], non_blocking=True)
+    job.keep.append(chunks)
+    job.tree.make_packed_views(group, chk, off, chunks, bases)
+    return True
+
+
 def _coalesced_d2h(job: _Job, lib, small: np.ndarray, sdev: torch.device, side) -> bool:
     """Many small device tensors -> ONE device gather kernel (accv_mtc_coalesce) -> ONE D2H transfer per chunk -> host
     views (the reference copies each tensor separately, multi_tensor_copier.cpp:790-800)."""
@@ -382,7 +488,7 @@ def _coalesced_d2h(job: _Job, lib, small: np.ndarray, sdev: torch.device, side) 
             table[:, 0] = ptrs[sel].view(np.int64)
             table[:, 1] = off[sel]
             table[:, 2] = sbytes[sel]
-            items = torch.from_numpy(table).to(sdev)
+            items = _item_table_to_device(job, lib, table, sdev, side)
             packed = torch.empty(size + 16, dtype=torch.uint8, device=sdev)
             _nat.check(lib.accv_mtc_coalesce(items.data_ptr(), len(sel), packed.data_ptr(), 0, side.cuda_stream),
                        "mtc_coalesce")
@@ -398,6 +504,10 @@ def _abandon(job: _Job) -> None:
     """A copy failed half way: wait for whatever was already enqueued on the side streams (the completion event may
     never have been recorded), then hand the staging blocks back."""
     try:
+        if job.ticket is not None:          # let the native job finish before its staging blocks are recycled
+            ticket, job.ticket = job.ticket, None
+            _nat.ctypes_lib().accv_mtc_async_wait(ticket)
+        job.pending_views = None
         for ev in job.events:
             ev.synchronize()
         devs = set(job.source_events)
@@ -436,17 +546,32 @@ class AsyncCopyHandle:
         self._future = future
         self._result = None
         self._consumed = False
+        self._error: Optional[BaseException] = None
 
     def _worker_result(self) -> None:
         """Re-raise a worker exception — after the transfers that were already enqueued have drained and the arena
         blocks acquired before the failure went back (otherwise they would leak for the life of the process, and the
         keep-alives of an active DMA would be dropped with the handle)."""
-        if self._future is None:
-            return
+        job = self._job
+        if self._error is not None:              # a failed copy keeps failing (the reference stores and rethrows it)
+            raise self._error
         try:
-            self._future.result()
-        except BaseException:
-            _abandon(self._job)
+            if job.pending_views is not None:
+                # native orchestration: the typed views only need the plan and the chunks, so they are built here, on the
+                # consumer's thread, WHILE the library thread stages and enqueues
+                views, job.pending_views = job.pending_views, None
+                job.tree.make_packed_views(*views)
+            if job.ticket is not None:
+                ticket, job.ticket = job.ticket, None
+                _nat.check(_nat.lib().accv_mtc_async_wait(ticket), "mtc_async_wait")   # ctypes: lock released
+                done = torch.cuda.Event()
+                done.record(job.side)          # every transfer of the job is on the side stream by now
+                job.events.append(done)
+            if self._future is not None:
+                self._future.result()
+        except BaseException as e:
+            self._error = e
+            _abandon(job)
             raise
 
     def _finish(self) -> None:
@@ -459,10 +584,11 @@ class AsyncCopyHandle:
 
     def ready(self) -> bool:
         """True once the copy has completed (non-blocking).  Raises if the copy failed."""
-        if self._future is not None:
-            if not self._future.done():
-                return False
-            self._worker_result()
+        if self._future is not None and not self._future.done():
+            return False
+        if self._job.ticket is not None and _nat.lib().accv_mtc_async_poll(self._job.ticket) == 0:
+            return False
+        self._worker_result()
         if all(ev.query() for ev in self._job.events):
             self._job.release_staging()
             return True
@@ -531,11 +657,22 @@ def start_copy(data, device, *, use_pinned_staging: bool = True, pack_cpu_tensor
     # ordering: capture the caller's current streams NOW (reference :1086-1123)
     if dev.type == "cuda":
         job.caller_stream = torch.cuda.current_stream(dev)
-    for dev_index in np.unique(didx[(route >= R_D2H_SMALL) & (route <= R_D2D)]).tolist():
+    if os.environ.get("ACCV_MTC_D2D_SAME_DEVICE") == "1" and dev.type == "cuda":
+        # test hook for one-GPU boxes: treat small tensors that already sit on the target device as if they came from
+        # another GPU, so that the coalesced GPU->GPU path runs (gather kernel + one copy + views) — results are copies
+        small = (route == R_REUSE) & (nbytes_all(job) > 0) & (nbytes_all(job) <= PACK_MAX_BYTES_PER_TENSOR) & (didx == dev.index)
+        route[small] = R_D2D_SMALL
+    for dev_index in np.unique(didx[((route >= R_D2H_SMALL) & (route <= R_D2D)) | (route == R_D2D_SMALL)]).tolist():
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(torch.device("cuda", int(dev_index))))
         job.source_events[int(dev_index)] = ev
     if use_background_thread:
+        try:
+            if _start_native_h2d(job):          # native library thread: no python worker, no interpreter-lock hand-offs
+                return AsyncCopyHandle(job, None)
+        except BaseException:
+            _abandon(job)
+            raise
         return AsyncCopyHandle(job, _executor().submit(_run, job))
     try:
         _run(job)  # inline: exceptions propagate from start_copy (reference :1151-1153)

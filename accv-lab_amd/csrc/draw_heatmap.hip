@@ -52,6 +52,7 @@ struct SplatParams {
     float factor, k;
     int counts_i64;
     int grid3d;           // tile index comes from a 3-D grid instead of a linear block index
+    float dense_area;     // SM == 5: a plane whose objects cover at least this many pixels (sum (2r+1)^2) stores write-through
     // multi-scale front end (SRC == 1): objects are float centres / boxes in source pixels, converted per scale
     const float* centers_f;  // [B, n_max, 2] (x, y)
     const float* boxes_f;    // [B, n_max, 4] (x0, y0, x1, y1)
@@ -270,11 +271,16 @@ __device__ __forceinline__ void splat_body(const SplatParams& p, long long linea
         for (int c = 0; c < PX; ++c) acc[i][c] = init;
 
     int total_hits = 0;
+    float cover = 0.0f;  // SM == 5: this lane's share of sum (2r+1)^2 over the plane's objects (density estimate)
 
     for (int base = 0; base < n; base += kCand) {
         // ---- cull: conservative 32-bit test, ballot, popcount-prefix compaction into LDS
         int x, y, r;
         const unsigned long long m = cull_round<SRC>(t, base, lane, x, y, r);
+        if constexpr (SM == 5) {
+            const float dia = (float)(2 * min(max(r, 0), 1 << 20) + 1);
+            cover += (base + lane < n) ? dia * dia : 0.0f;
+        }
         const bool hit = (m >> lane) & 1ull;
         const int nh = __popcll(m);
         if (nh == 0) continue;
@@ -371,6 +377,17 @@ __device__ __forceinline__ void splat_body(const SplatParams& p, long long linea
 
     using V = typename Vec<PX>::type;
     float* plane_ptr = p.hm + (size_t)plane * (size_t)p.H * (size_t)p.W;
+    // SM == 5 (in-place launches): the store policy is chosen PER PLANE from the density of its objects, known to the
+    // wave for free after its cull loop: sum (2r+1)^2 over the plane's objects relative to the plane's area.  Planes that
+    // are covered about once or more rewrite most of their tiles -> write-through non-temporal stores (sc1 nt: -6 % on
+    // the dense rule-A batch); sparse planes touch a few tiles that the next consumer finds in L2 / Infinity Cache ->
+    // plain stores (write-through costs them 27 %, profiles/r01_h1_ab_rows_store_policy.log).  Same values either way.
+    bool write_through = SM == 2 || SM == 4;
+    if constexpr (SM == 5 && PX == 4) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cover += __shfl_xor(cover, d);
+        write_through = cover >= p.dense_area;   // wave-uniform
+    }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int row = ty0 + sub * R + i;
@@ -386,8 +403,12 @@ __device__ __forceinline__ void splat_body(const SplatParams& p, long long linea
         } else if constexpr (SM >= 2 && PX == 4) {
             // write-through (sc1) / write-through non-temporal (sc1 nt) 16-byte buffer store
             constexpr int aux = SM == 2 ? 16 : 18;  // sc1 | sc1+nt
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(out, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, aux);
+            if (write_through) {
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(out, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, aux);
+            } else {
+                *dst = out;
+            }
         } else {
             *dst = out;
         }
@@ -830,6 +851,14 @@ int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_
             case 2: ACCV_LAUNCH_SM(2); break;
 #endif
             case 4: ACCV_LAUNCH_SM(4); break;
+            case 5:  // density-adaptive (in-place launches only; a fused-clear launch asking for it gets plain stores)
+                if (clear) {
+                    sm = 0;
+                    ACCV_LAUNCH_SM(0);
+                } else {
+                    hipLaunchKernelGGL((splat_kernel<PX, R, false, 5, WPG>), grid, block, 0, stream, p);
+                }
+                break;
             default: sm = 0; ACCV_LAUNCH_SM(0); break;
         }
     } else {
@@ -853,8 +882,16 @@ int dispatch_splat(SplatParams p, long long planes, bool clear, unsigned flags, 
     const size_t total_bytes = (size_t)planes * p.H * p.W * sizeof(float);
     const bool plane_fits_rsrc = (size_t)p.H * p.W * sizeof(float) < ((size_t)1 << 31);
     int nt = accv::tune_get("hm_nt", -1);
-    if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;
+    if (nt < 0) {
+        if (flags & ACCV_HM_WRITE_THROUGH)
+            nt = 4;
+        else if (flags & ACCV_HM_PLAIN_STORES)
+            nt = 0;
+        else
+            nt = clear ? 0 : 5;   // in-place: per-plane choice by object density (see the store loop of splat_body)
+    }
     if (nt >= 2 && !plane_fits_rsrc) nt = 0;
+    p.dense_area = 0.75f * (float)p.H * (float)p.W;
     int rows = accv::tune_get("hm_rows", -1);
     if (rows < 0) {
         if (flags & ACCV_HM_TILE_ROWS_16)

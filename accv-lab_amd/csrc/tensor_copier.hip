@@ -240,6 +240,112 @@ __global__ __launch_bounds__(256) void coalesce_kernel(const CopyItem* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------ native orchestration
+extern "C" int accv_mtc_stage_h2d(long long, const void* const*, const long long*, const long long*, const long long*,
+                                  long long, const long long*, void* const*, void* const*, const long long*, void*, int);
+
+struct AsyncStage {
+    std::vector<const void*> src;
+    std::vector<long long> nbytes, offset, order, item_begin, chunk_bytes;
+    std::vector<void*> staging, device;
+    long long n_items = 0, n_chunks = 0;
+    void* stream = nullptr;
+    int threads = 0, device_index = 0;
+    // result
+    bool done = false;
+    int status = 0;
+    char error[512] = {0};
+};
+
+// ONE persistent thread executes the queued jobs in order (a job already fans its memcpy out over the worker pool);
+// tickets stay valid until waited for once.
+class Orchestrator {
+public:
+    static Orchestrator& instance()
+    {
+        static Orchestrator o;
+        return o;
+    }
+    long long submit(const std::shared_ptr<AsyncStage>& job)
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (!started_) {
+            started_ = true;
+            thread_ = std::thread([this] { loop(); });
+        }
+        const long long id = ++next_id_;
+        jobs_[id] = job;
+        queue_.push_back(job);
+        cv_.notify_all();
+        return id;
+    }
+    // block = true: wait for the job, forget the ticket, return its status; block = false: 1 done / 0 running
+    int wait(long long ticket, bool block)
+    {
+        std::unique_lock<std::mutex> lock(mutex_);
+        auto it = jobs_.find(ticket);
+        if (it == jobs_.end()) return accv::fail(ACCV_EINVAL, "mtc async: unknown ticket %lld", ticket);
+        std::shared_ptr<AsyncStage> job = it->second;
+        if (!block) return job->done ? 1 : 0;
+        done_cv_.wait(lock, [&] { return job->done; });
+        jobs_.erase(it);
+        if (job->status != ACCV_OK) snprintf(accv::error_buffer(), 512, "%s", job->error);
+        return job->status;
+    }
+
+private:
+    ~Orchestrator()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (thread_.joinable()) thread_.join();
+    }
+    void loop()
+    {
+        int current_device = -1;
+        for (;;) {
+            std::shared_ptr<AsyncStage> job;
+            {
+                std::unique_lock<std::mutex> lock(mutex_);
+                cv_.wait(lock, [&] { return stop_ || !queue_.empty(); });
+                if (stop_) return;
+                job = queue_.front();
+                queue_.erase(queue_.begin());
+            }
+            int rc = ACCV_OK;
+            if (job->device_index != current_device) {
+                if (hipSetDevice(job->device_index) != hipSuccess) {
+                    (void)hipGetLastError();
+                    rc = accv::fail(ACCV_ELAUNCH, "mtc async: hipSetDevice(%d) failed", job->device_index);
+                } else {
+                    current_device = job->device_index;
+                }
+            }
+            if (rc == ACCV_OK)
+                rc = accv_mtc_stage_h2d(job->n_items, job->src.data(), job->nbytes.data(), job->offset.data(), job->order.data(),
+                                        job->n_chunks, job->item_begin.data(), job->staging.data(), job->device.data(),
+                                        job->chunk_bytes.data(), job->stream, job->threads);
+            {
+                std::lock_guard<std::mutex> lock(mutex_);
+                job->status = rc;
+                if (rc != ACCV_OK) snprintf(job->error, sizeof job->error, "%s", accv::error_buffer());   // this thread's message
+                job->done = true;
+            }
+            done_cv_.notify_all();
+        }
+    }
+    std::mutex mutex_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::shared_ptr<AsyncStage>> queue_;
+    std::map<long long, std::shared_ptr<AsyncStage>> jobs_;
+    std::thread thread_;
+    long long next_id_ = 0;
+    bool started_ = false, stop_ = false;
+};
+
 }  // namespace
 
 extern "C" {
@@ -372,6 +478,44 @@ int accv_mtc_stage_h2d(long long n_items, const void* const* src, const long lon
     }
     return ACCV_OK;
 }
+
+/* ---- the same staging + transfer on a NATIVE orchestration thread (the reference's CopyThreadPool worker,
+ * multi_tensor_copier.cpp:288-349, 863-883): the call copies its argument arrays, queues the job and returns a ticket at
+ * once; a library thread (no Python, no GIL) runs accv_mtc_stage_h2d on `device_index`; accv_mtc_async_wait blocks until
+ * the transfers of that job have been ENQUEUED on the stream (not completed: the caller records / synchronises a stream
+ * event afterwards) and returns the job's status (its error text becomes the waiting thread's accv_last_error). */
+int accv_mtc_stage_h2d_async(long long n_items, const void* const* src, const long long* nbytes, const long long* offset,
+                             const long long* order, long long n_chunks, const long long* item_begin,
+                             void* const* staging, void* const* device, const long long* chunk_bytes, void* stream,
+                             int threads, int device_index, long long* ticket_out)
+{
+    if (!ticket_out) return accv::fail(ACCV_EINVAL, "mtc_stage_h2d_async: null ticket pointer");
+    if (n_items < 0 || n_chunks < 0) return accv::fail(ACCV_EINVAL, "mtc_stage_h2d_async: negative count");
+    if (n_chunks > 0 && (!src || !nbytes || !offset || !order || !item_begin || !staging || !device || !chunk_bytes))
+        return accv::fail(ACCV_EINVAL, "mtc_stage_h2d_async: null array");
+    auto job = std::make_shared<AsyncStage>();
+    job->src.assign(src, src + (n_chunks ? n_items : 0));
+    job->nbytes.assign(nbytes, nbytes + (n_chunks ? n_items : 0));
+    job->offset.assign(offset, offset + (n_chunks ? n_items : 0));
+    job->order.assign(order, order + (n_chunks ? n_items : 0));
+    job->item_begin.assign(item_begin, item_begin + (n_chunks ? n_chunks + 1 : 0));
+    job->staging.assign(staging, staging + n_chunks);
+    job->device.assign(device, device + n_chunks);
+    job->chunk_bytes.assign(chunk_bytes, chunk_bytes + n_chunks);
+    job->n_items = n_items;
+    job->n_chunks = n_chunks;
+    job->stream = stream;
+    job->threads = threads;
+    job->device_index = device_index;
+    *ticket_out = Orchestrator::instance().submit(job);
+    return ACCV_OK;
+}
+
+int accv_mtc_async_wait(long long ticket) { return Orchestrator::instance().wait(ticket, true); }
+
+/* 1 = the job has finished (successfully or not; its status is what accv_mtc_async_wait returns), 0 = still running,
+ * negative = unknown ticket. */
+int accv_mtc_async_poll(long long ticket) { return Orchestrator::instance().wait(ticket, false); }
 
 /* Device-side coalescing: items[k] = {device src pointer, byte offset inside `packed`, nbytes}; `items` must be
  * readable from the device (device memory or pinned host memory).  scatter == 0 gathers src -> packed + offset,

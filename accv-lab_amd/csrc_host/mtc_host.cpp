@@ -22,7 +22,7 @@ constexpr int64_t kPackMaxBytes = 256 * 1024;  // multi_tensor_copier.cpp:483
 enum Kind : uint8_t { kList = 0, kTuple = 1, kDict = 2, kLeaf = 3, kPass = 4 };
 
 // classification of a leaf relative to the target device
-enum Route : int8_t { kExternal = -1, kReuse = 0, kH2DPack = 1, kH2DSingle = 2, kD2HSmall = 3, kD2HOther = 4, kD2D = 5, kOther = 6 };
+enum Route : int8_t { kExternal = -1, kReuse = 0, kH2DPack = 1, kH2DSingle = 2, kD2HSmall = 3, kD2HOther = 4, kD2D = 5, kOther = 6, kD2DSmall = 7 };
 
 struct Op {
     uint8_t kind;
@@ -189,7 +189,7 @@ public:
             } else if (t.device().is_cuda() && target.is_cpu()) {
                 k = (pack && small) ? kD2HSmall : kD2HOther;
             } else if (t.device().is_cuda() && target.is_cuda()) {
-                k = kD2D;
+                k = (pack && small) ? kD2DSmall : kD2D;
             } else {
                 k = kOther;
             }

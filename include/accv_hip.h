@@ -41,6 +41,9 @@ extern "C" {
 #define ACCV_HM_GROUP_BOXES_GIVEN 16u /* accv_draw_points_multiscale_f32 only: `workspace` already holds the group boxes
                                          (written by accv_polyline_sample_boxes); skip the box launch */
 
+#define ACCV_HM_PLAIN_STORES 128u /* hint: plain stores for every plane.  Default: fused-clear launches store plain; in-place
+                                    launches choose per plane — write-through non-temporal where the plane's objects
+                                    cover >= 3/4 of its area (sum of (2r+1)^2), plain elsewhere.  Same results. */
 #define ACCV_HM_TILE_ROWS_16 32u /* hint: 128 x 32 pixel tiles (default only for fused-clear launches above 128 MB) */
 #define ACCV_HM_TILE_ROWS_8 64u  /* hint: 128 x 16 pixel tiles (default for everything else).  Same results either way. */
 
@@ -182,6 +185,26 @@ int accv_ragged_accumulate(const void* src, void* dst, const void* src_indices_o
 int accv_ragged_mask_to_indices(const void* mask_u8, const void* valid_counts_or_null, int valid_i64, long long batch,
                                 long long width, long long* out_indices, long long* out_sizes, void* stream);
 
+/* F3 — matched gather + element-wise loss + masked per-sample sum in ONE launch.  The caller pattern of
+ * packages/batching_helpers/example/loss_computation.py:37-43 (batched_indexing_access of ground truth and prediction
+ * through the two index lists of a matching) and :85-86 (sum_over_targets of the per-object loss):
+ *   out[i] = sum_{j < counts[i]} w * sum_k l(a[i, idx_a[i,j], k] - b[i, idx_b[i,j], k]),  w = weights[i, idx_a[i,j]] or 1
+ * kind: 0 = |d| (L1), 1 = d^2, 2 = smooth-L1 with `beta` (torch.nn.functional.smooth_l1_loss).  a f32[batch, w_a, row],
+ * b f32[batch, w_b, row], indices [batch, idx_stride] int32/int64 (first w_idx slots), counts int32/int64, out f32[batch].
+ * Deterministic (fixed-order tree reduction per sample).  Pairs with an out-of-range index contribute nothing. */
+int accv_matched_pair_reduce_f32(const float* a, const float* b, const void* idx_a, const void* idx_b, const void* counts,
+                                 const float* weights_or_null, long long batch, long long w_a, long long w_b,
+                                 long long w_idx, long long idx_stride, long long row_elems, int kind, float beta,
+                                 int idx_i64, int counts_i64, float* out, void* stream);
+/* Its backward: grad_a[i, idx_a[i,j], k] += g[i] * w * l'(d), grad_b[...] -= the same, grad_w[i, idx_a[i,j]] += g[i] * l(d)
+ * (float atomics; the gradient tensors must be zero-initialised by the caller; any of them may be NULL). */
+int accv_matched_pair_reduce_bwd_f32(const float* a, const float* b, const void* idx_a, const void* idx_b,
+                                     const void* counts, const float* weights_or_null, const float* grad_out,
+                                     long long batch, long long w_a, long long w_b, long long w_idx,
+                                     long long idx_stride, long long row_elems, int kind, float beta, int idx_i64,
+                                     int counts_i64, float* grad_a_or_null, float* grad_b_or_null,
+                                     float* grad_w_or_null, void* stream);
+
 /* combine_data / split on device (batched_processing_py.py:410-423, ragged_batch.py:870-934):
  * unpack == 0: padded[i, j, :] = flat[offsets[i] + j, :] for j < sizes[i], zero bytes elsewhere;
  * unpack != 0: the inverse copy (flat <- padded, valid entries only).  offsets/sizes are device int64. */
@@ -226,6 +249,19 @@ int accv_mtc_pack_host(long long n_items, const void* const* src, const long lon
 int accv_mtc_stage_h2d(long long n_items, const void* const* src, const long long* nbytes, const long long* offset,
                        const long long* order, long long n_chunks, const long long* item_begin, void* const* staging,
                        void* const* device, const long long* chunk_bytes, void* stream, int threads);
+
+/* The same staging + transfers on a native orchestration thread of the library (counterpart of the reference's
+ * CopyThreadPool worker running schedule_copies, multi_tensor_copier.cpp:288-349, 863-883): the argument arrays are copied,
+ * the job is queued and `*ticket_out` returned at once; no Python and no interpreter lock are involved in the work.
+ * accv_mtc_async_wait(ticket) blocks until every transfer of the job has been ENQUEUED on `stream` (completion is the
+ * caller's stream event) and returns the job's status; accv_mtc_async_poll(ticket) is 1 when it has finished, else 0.
+ * A ticket is forgotten by the wait that returns its status. */
+int accv_mtc_stage_h2d_async(long long n_items, const void* const* src, const long long* nbytes, const long long* offset,
+                             const long long* order, long long n_chunks, const long long* item_begin,
+                             void* const* staging, void* const* device, const long long* chunk_bytes, void* stream,
+                             int threads, int device_index, long long* ticket_out);
+int accv_mtc_async_wait(long long ticket);
+int accv_mtc_async_poll(long long ticket);
 
 /* One kernel that gathers (scatter == 0) many small device tensors into `packed`, or fans `packed` out again
  * (scatter != 0).  items: array of {const void* ptr; long long offset_in_packed; long long nbytes;} readable by

@@ -21,7 +21,7 @@ def main(out):
     res = {}
     trace = rows(os.path.join(out, "trace", "**", "*kernel_trace.csv"))
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace
-           if "splat_kernel" in r["Kernel_Name"] and "true" in r["Kernel_Name"].split("splat_kernel")[1][:20]]
+           if "splat_kernel<" in r["Kernel_Name"] and "true" in r["Kernel_Name"].split("splat_kernel")[1][:20]]
     if dur:
         res["clear_kernel"] = {"name": next(r["Kernel_Name"] for r in trace if "splat_kernel" in r["Kernel_Name"]),
                                "launches": len(dur), "avg_us_all": sum(dur) / len(dur) / 1e3,
@@ -46,6 +46,19 @@ def main(out):
     fi = res.get("FETCH_SIZE_KB_per_launch", {}).get("inplace")
     if wi is not None and fi is not None:
         res["hbm_bytes_per_launch_inplace"] = int(wi * 1024 + 2 * fi * 1024)
+    # traffic record for bench.py (roofline.traffic): names the kernel instantiation the PMC passes ran on, so that a
+    # later bench run only quotes it while it still dispatches the same one
+    try:
+        with open(os.path.join(out, "bench_write.json")) as fh:
+            bw = json.loads([l for l in fh.read().splitlines() if l.startswith("{")][-1])
+        if "hbm_bytes_per_launch_clear" in res:
+            res["traffic_record"] = {"kernel": bw["roofline"]["kernel"].split(" grid")[0],
+                                     "hbm_bytes_per_launch": res["hbm_bytes_per_launch_clear"],
+                                     "write_size_kb": w, "fetch_size_kb_raw": f,
+                                     "method": "separate rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes over bench.py; "
+                                               "FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md)"}
+    except Exception as e:  # noqa: BLE001
+        res["traffic_record"] = f"unavailable: {e}"
     try:
         with open(os.path.join(out, "bench_under_rocprof.json")) as fh:
             line = [l for l in fh.read().splitlines() if l.startswith("{")][-1]

@@ -23,7 +23,8 @@ def rb(t, sizes):
 
 
 _VARIANTS = {"shipped": 0, "rows16": "HM_TILE_ROWS_16", "rows16-wt-nt": ("HM_TILE_ROWS_16", "HM_WRITE_THROUGH"),
-             "rows8-wt-nt": ("HM_TILE_ROWS_8", "HM_WRITE_THROUGH"), "small-splat": "HM_SMALL_RADII"}
+             "rows8-wt-nt": ("HM_TILE_ROWS_8", "HM_WRITE_THROUGH"), "small-splat": "HM_SMALL_RADII",
+             "plain-stores": "HM_PLAIN_STORES"}
 
 
 @pytest.fixture(autouse=True, params=list(_VARIANTS), ids=list(_VARIANTS))
@@ -451,6 +452,12 @@ def test_dispatch_string_follows_the_public_hints(kernel_variant):
         assert ("R=16" in s) == kernel_variant.startswith("rows16")
     assert ("SM=4" in s) == kernel_variant.endswith("wt-nt")
     assert "CLEAR=1" in s and "block(64)" in s
+    # in-place launches choose their stores per plane unless a hint fixes the policy
+    draw_heatmap_batched(hm, rb(c, n), rb(r, n))
+    s = nat.last_dispatch()
+    if kernel_variant != "small-splat":
+        want = "SM=4" if kernel_variant.endswith("wt-nt") else "SM=0" if kernel_variant == "plain-stores" else "SM=5"
+        assert want in s and "CLEAR=0" in s
     # a map whose width is not a multiple of 4 takes the scalar instantiation whatever the hints say
     odd = torch.zeros(1, 8, 30, device=DEV)
     draw_heatmap_batched(odd, rb(c[:1], n[:1]), rb(r[:1], n[:1]))

@@ -142,7 +142,8 @@ def test_store_policy_hints_do_not_change_results(clear):
     base = torch.rand(b, h, w, generator=g).mul_(0.2).to(DEV)
     ref = base.clone()
     draw_heatmap_batched(ref, rb(centers), rb(radii), clear=clear)
-    for kw in ({"write_through": True}, {"small_radii": True}, {"write_through": True, "small_radii": True}):
+    for kw in ({"write_through": True}, {"write_through": False}, {"small_radii": True},
+               {"write_through": True, "small_radii": True}):
         got = base.clone()
         draw_heatmap_batched(got, rb(centers), rb(radii), clear=clear, **kw)
         if kw.get("small_radii"):
@@ -155,3 +156,37 @@ def test_store_policy_hints_do_not_change_results(clear):
     draw_heatmap(flat_wt, centers.reshape(-1, 2).contiguous(), radii.reshape(-1).contiguous(), idx, clear=clear,
                  write_through=True)
     assert torch.equal(flat_ref, flat_wt)
+
+
+def test_density_adaptive_store_policy_is_value_neutral():
+    """in-place launches pick write-through or plain stores PER PLANE from sum (2r+1)^2 of the plane's objects (>= 3/4 of
+    the plane's area -> write-through): a batch that mixes dense and sparse planes must equal the forced-plain and the
+    forced-write-through results bit for bit, class-wise too"""
+    from types import SimpleNamespace
+
+    from accvlab.draw_heatmap import draw_heatmap_batched
+
+    g = torch.Generator().manual_seed(11)
+    b, n, h, w = 6, 40, 96, 256
+    centers = torch.stack([torch.randint(0, w, (b, n), generator=g), torch.randint(0, h, (b, n), generator=g)], -1).to(torch.int32)
+    radii = torch.randint(1, 4, (b, n), generator=g).to(torch.int32)
+    radii[0] = 60                                       # plane 0: 40 objects of 121 x 121 -> far above the threshold
+    radii[3, :2] = 80                                   # plane 3: two large objects -> 2 * 161^2 = 2.1 x the plane
+    counts = torch.tensor([40, 40, 0, 2, 7, 40])
+    labels = torch.randint(0, 3, (b, n), generator=g).to(torch.int32)
+    rb = lambda t: SimpleNamespace(tensor=t.to(DEV), sample_sizes=counts.to(DEV))  # noqa: E731
+    base = torch.rand(b, h, w, generator=g).mul_(0.3).to(DEV)
+    outs = []
+    for wt in (None, False, True):
+        hm = base.clone()
+        draw_heatmap_batched(hm, rb(centers), rb(radii), 6.0, 0.9, write_through=wt)
+        outs.append(hm)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert bool((outs[0] != base).any())
+    base4 = torch.rand(b, 3, h, w, generator=g).mul_(0.3).to(DEV)
+    outs = []
+    for wt in (None, False, True):
+        hm = base4.clone()
+        draw_heatmap_batched(hm, rb(centers), rb(radii), 6.0, 0.9, rb(labels), write_through=wt)
+        outs.append(hm)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
