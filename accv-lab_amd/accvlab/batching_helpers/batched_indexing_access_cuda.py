@@ -17,6 +17,29 @@ import torch
 
 from .. import _amd_native as _nat
 
+try:  # C++ fast path of the hottest operators (csrc_host/bh_host.cpp); the python code below is complete without it
+    from . import _bh_host as _bh
+except ImportError:  # pragma: no cover
+    _bh = None
+_native_bound = False
+
+
+def _native():
+    """_bh_host with the C-ABI addresses bound (same library handle as the ctypes binding), or None."""
+    global _native_bound
+    if _bh is None or not hasattr(_bh, "bind_native"):
+        return None
+    if not _native_bound:
+        import ctypes
+
+        h = _nat.ctypes_lib()
+        addr = lambda name: ctypes.cast(getattr(h, name), ctypes.c_void_p).value  # noqa: E731
+        _bh.bind_native(addr("accv_ragged_gather"), addr("accv_ragged_scatter"), addr("accv_ragged_gather_fill"),
+                        addr("accv_last_error"))
+        _native_bound = True
+    return _bh
+
+
 _COPY_DTYPES = {torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.int32, torch.int64}
 _ACC_CODE = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3, torch.float16: 4, torch.bfloat16: 5}
 _INDEX_DTYPES = (torch.int32, torch.int64)
@@ -91,6 +114,7 @@ def _data_dtype(t, name, allow_bool=False) -> None:
 
 
 @functools.lru_cache(maxsize=256)
+@functools.lru_cache(maxsize=256)
 def element_bits(value, dtype: torch.dtype) -> int:
     """Byte pattern (as an unsigned integer, little endian) of ``value`` converted to ``dtype`` with the
     conversion rules of ``static_cast<scalar_t>(double)`` used by the reference."""
@@ -134,6 +158,13 @@ def forward(input_data: torch.Tensor, input_indices: torch.Tensor, input_nums_in
             fill_value: float = 0.0) -> torch.Tensor:
     """``res[i, j] = input_data[i, input_indices[i, j]]`` for ``j < input_nums_indices[i]``, ``fill_value``
     elsewhere (cpp:54-86, kernel cu:52-113 forward direction)."""
+    nat = _native()
+    if nat is not None and type(input_data) is torch.Tensor and input_data.dtype in _COPY_DTYPES:
+        # checks, allocation, stream and the C-ABI call in C++; it declines (None) whatever the python path below must
+        # diagnose or handle (wrong devices / dtypes / shapes, empty results)
+        res = nat.forward_gather_fill(input_data, input_indices, input_nums_indices, element_bits(fill_value, input_data.dtype))
+        if res is not None:
+            return res.requires_grad_(True) if input_data.requires_grad else res
     _contig(input_data, "input_data")
     _contig(input_indices, "input_indices")
     _contig(input_nums_indices, "input_nums_indices")
@@ -399,6 +430,9 @@ def mask_to_indices(mask: torch.Tensor, valid_counts: Optional[torch.Tensor] = N
 def gather_rows(src: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor, w_idx: int, out: torch.Tensor) -> None:
     """(extension) ``out[i, j] = src[i, indices[i, j]]`` for j < counts[i], j < w_idx, where ``indices`` may be
     wider than ``w_idx`` (row stride = indices.size(1)); any dtype incl. bool; single batch dimension."""
+    nat = _native()
+    if nat is not None and nat.gather_rows(src, indices, counts, int(w_idx), out):
+        return
     if not (src.is_contiguous() and out.is_contiguous() and indices.is_contiguous()):
         raise RuntimeError("gather_rows: contiguous tensors required")
     if out.numel() == 0 or w_idx == 0:
@@ -413,6 +447,9 @@ def gather_rows(src: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor, 
 
 def scatter_rows(src: torch.Tensor, indices: torch.Tensor, counts: torch.Tensor, w_idx: int, out: torch.Tensor) -> None:
     """(extension) ``out[i, indices[i, j]] = src[i, j]`` for j < counts[i], j < w_idx (src width == w_idx)."""
+    nat = _native()
+    if nat is not None and nat.scatter_rows(src, indices, counts, int(w_idx), out):
+        return
     if not (src.is_contiguous() and out.is_contiguous() and indices.is_contiguous()):
         raise RuntimeError("scatter_rows: contiguous tensors required")
     if src.numel() == 0 or w_idx == 0:

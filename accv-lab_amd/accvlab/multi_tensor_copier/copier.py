@@ -41,6 +41,7 @@ except ImportError:  # pragma: no cover - exercised when the host extension has 
     _host = None
 
 PACK_MAX_BYTES_PER_TENSOR = 256 * 1024  # multi_tensor_copier.cpp:483
+_NATIVE_THREAD_MIN_BYTES = 2 << 20      # background jobs below this stage on the caller's thread (thread wake-ups cost more)
 R_REUSE, R_H2D_PACK, R_H2D_SINGLE, R_D2H_SMALL, R_D2H_OTHER, R_D2D, R_OTHER, R_D2D_SMALL = range(8)
 
 _pool_lock = threading.Lock()
@@ -288,6 +289,15 @@ def _start_native_h2d(job: _Job) -> bool:
         prep = _prepare_packed_h2d(job, lib, packable, side)
         if prep is None:
             return False
+        if int(prep["arrays"][1].sum()) <= _NATIVE_THREAD_MIN_BYTES:
+            # a few hundred KB stage in tens of microseconds: waking another thread (and being woken by it) costs more
+            # than the memcpy — stage here, the transfer itself is asynchronous on the side stream either way
+            _nat.check(lib.accv_mtc_stage_h2d(*prep["stage_args"], side.cuda_stream, 0), "mtc_stage_h2d")
+            done = torch.cuda.Event()
+            done.record(side)
+            job.events.append(done)
+            job.pending_views = prep["views"]
+            return True
         ticket = ctypes.c_longlong(0)
         _nat.check(lib.accv_mtc_stage_h2d_async(*prep["stage_args"], side.cuda_stream, 0, job.device.index,
                                                 ctypes.addressof(ticket)), "mtc_stage_h2d_async")
@@ -670,9 +680,11 @@ def start_copy(data, device, *, use_pinned_staging: bool = True, pack_cpu_tensor
         try:
             if _start_native_h2d(job):          # native library thread: no python worker, no interpreter-lock hand-offs
                 return AsyncCopyHandle(job, None)
-        except BaseException:
+        except Exception as e:                  # background mode reports failures from ready() / get(), as a worker would
             _abandon(job)
-            raise
+            failed = AsyncCopyHandle(job, None)
+            failed._error = e
+            return failed
         return AsyncCopyHandle(job, _executor().submit(_run, job))
     try:
         _run(job)  # inline: exceptions propagate from start_copy (reference :1151-1153)

@@ -874,12 +874,13 @@ int dispatch_splat(SplatParams p, long long planes, bool clear, unsigned flags, 
 {
     const bool small_hint = (flags & ACCV_HM_SMALL_RADII) != 0;
     const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.hm) & 15u) == 0);
-    // Store policy and tile height, from in-process A/B runs on ten boxes (profiles/r01_h1_ab_rows_store_policy.log):
-    // plain stores everywhere unless the caller asks for write-through ones, and for fused-clear launches far larger than
-    // L2 + Infinity Cache a 128 x 32 tile (R = 16: -4..-7 % on the slower boxes, +-0.5 % on the fastest); in-place
-    // launches and small maps keep 128 x 16 (more waves, less read-modify-write per touched tile).  The caller's
-    // ACCV_HM_TILE_ROWS_* hints override the size rule.  No knob table, mutex or string look-up on this path.
-    const size_t total_bytes = (size_t)planes * p.H * p.W * sizeof(float);
+    // Tile height: 128 x 16 pixel tiles (R = 8) for every launch.  Round 1 shipped 128 x 32 for fused-clear launches above
+    // 128 MB after an A/B on nine boxes (profiles/r01_h1_ab_rows_store_policy.log: -4..-7 % there); with this round's
+    // build the same A/B on four boxes of the slow class puts R = 8 ahead by 1.1-2.8 % on the headline batch and 6 % on
+    // small-object batches (profiles/r02_h1_flags_ab_*.log), and in-place launches always preferred it.  R = 16 stays
+    // available as a hint (ACCV_HM_TILE_ROWS_16).  Store policy: plain stores for fused-clear launches; in-place launches
+    // decide per plane inside the kernel (SM = 5); ACCV_HM_WRITE_THROUGH / ACCV_HM_PLAIN_STORES override.  No knob table,
+    // mutex or string look-up on this path.
     const bool plane_fits_rsrc = (size_t)p.H * p.W * sizeof(float) < ((size_t)1 << 31);
     int nt = accv::tune_get("hm_nt", -1);
     if (nt < 0) {
@@ -899,7 +900,7 @@ int dispatch_splat(SplatParams p, long long planes, bool clear, unsigned flags, 
         else if (flags & ACCV_HM_TILE_ROWS_8)
             rows = 8;
         else
-            rows = (clear && total_bytes > ((size_t)128 << 20)) ? 16 : 8;
+            rows = 8;
     }
     if (!p.labels) p.labels = p.radii;  // branch-free candidate loads: always a readable array (ignored when cls < 0)
     if (!vec4) return launch_splat<1, 8>(p, planes, clear, 0, stream);

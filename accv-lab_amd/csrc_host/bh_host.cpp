@@ -4,14 +4,116 @@
 // Plumbing only — no device code, no HIP calls.  Anything unusual (mixed devices or dtypes, gradients, non-tensor
 // leaves) makes these functions decline (return None), and the python implementation handles it and raises the
 // reference's error messages.
+#include <c10/hip/HIPFunctions.h>
+#include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
 #include <cstring>
 #include <vector>
 
+#include "accv_hip.h"  // prototypes only: the entry points are called through addresses handed over by the python side
+
 namespace py = pybind11;
 
 namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Native fast path of the hottest ragged operators: argument checks, result allocation, current stream and ONE call
+// into the C-ABI of libaccv_hip.so, all in C++ (~1.5 us per call; the python formulation of the same steps costs
+// 6-11 us, more than the kernels run).  The function addresses come from the ctypes handle of the python package
+// (bind_native), so there is one copy of the library.  Anything unusual (other device current, non-contiguous or CPU
+// tensors, unsupported dtypes) makes these functions DECLINE (return None / false): the python implementation then
+// runs and raises the reference's error messages.
+struct NativeApi {
+    decltype(&accv_ragged_gather) gather = nullptr;
+    decltype(&accv_ragged_scatter) scatter = nullptr;
+    decltype(&accv_ragged_gather_fill) gather_fill = nullptr;
+    decltype(&accv_last_error) last_error = nullptr;
+} g_api;
+
+void bind_native(uint64_t gather, uint64_t scatter, uint64_t gather_fill, uint64_t last_error)
+{
+    g_api.gather = reinterpret_cast<decltype(g_api.gather)>(gather);
+    g_api.scatter = reinterpret_cast<decltype(g_api.scatter)>(scatter);
+    g_api.gather_fill = reinterpret_cast<decltype(g_api.gather_fill)>(gather_fill);
+    g_api.last_error = reinterpret_cast<decltype(g_api.last_error)>(last_error);
+}
+
+inline bool plain_cuda(const at::Tensor& t) { return t.defined() && t.is_cuda() && t.is_contiguous(); }
+inline int index_code(const at::Tensor& t) { return t.scalar_type() == at::kLong ? 1 : (t.scalar_type() == at::kInt ? 0 : -1); }
+inline bool on_current_device(const at::Tensor& t) { return (int)t.get_device() == (int)c10::hip::current_device(); }
+inline void* stream_of(const at::Tensor& t) { return c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+inline void check_status(int rc, const char* what)
+{
+    if (rc != 0) {
+        const char* msg = g_api.last_error ? g_api.last_error() : "";
+        TORCH_CHECK(false, what, ": ", msg ? msg : "error", " (status ", rc, ")");
+    }
+}
+inline int64_t row_elems(const at::Tensor& t, int64_t first)
+{
+    int64_t n = 1;
+    for (int64_t d = first; d < t.dim(); ++d) n *= t.size(d);
+    return n;
+}
+
+// out[i, j] = src[i, indices[i, j]] for j < counts[i], j < w_idx (single batch dimension); false = declined
+bool gather_rows(const at::Tensor& src, const at::Tensor& indices, const at::Tensor& counts, int64_t w_idx, const at::Tensor& out)
+{
+    if (!g_api.gather || !plain_cuda(src) || !plain_cuda(indices) || !plain_cuda(counts) || !plain_cuda(out)) return false;
+    if (src.dim() < 2 || indices.dim() != 2 || index_code(indices) < 0 || index_code(counts) < 0) return false;
+    if (!on_current_device(src) || indices.get_device() != src.get_device() || out.get_device() != src.get_device()) return false;
+    if (out.numel() == 0 || w_idx == 0) return true;
+    check_status(g_api.gather(src.data_ptr(), out.data_ptr(), indices.data_ptr(), counts.data_ptr(), src.size(0), src.size(1),
+                              w_idx, indices.size(1), row_elems(src, 2) * (int64_t)src.element_size(), index_code(indices),
+                              index_code(counts), nullptr, stream_of(src)),
+                 "gather_rows");
+    return true;
+}
+
+// out[i, indices[i, j]] = src[i, j] for j < counts[i], j < w_idx; false = declined
+bool scatter_rows(const at::Tensor& src, const at::Tensor& indices, const at::Tensor& counts, int64_t w_idx, const at::Tensor& out)
+{
+    if (!g_api.scatter || !plain_cuda(src) || !plain_cuda(indices) || !plain_cuda(counts) || !plain_cuda(out)) return false;
+    if (src.dim() < 2 || out.dim() < 2 || indices.dim() != 2 || index_code(indices) < 0 || index_code(counts) < 0) return false;
+    if (!on_current_device(src) || indices.get_device() != src.get_device() || out.get_device() != src.get_device()) return false;
+    if (src.numel() == 0 || w_idx == 0) return true;
+    check_status(g_api.scatter(src.data_ptr(), out.data_ptr(), indices.data_ptr(), counts.data_ptr(), src.size(0), w_idx,
+                               indices.size(1), out.size(1), row_elems(src, 2) * (int64_t)src.element_size(),
+                               index_code(indices), index_code(counts), nullptr, stream_of(src)),
+                 "scatter_rows");
+    return true;
+}
+
+// batched_indexing_access_cuda.forward (reference cpp:54-86): result [*batch, K, *data] = gathered rows, `fill_bits`
+// (the filler's little-endian byte pattern in the data type) elsewhere; None = declined
+py::object forward_gather_fill(const at::Tensor& data, const at::Tensor& indices, const at::Tensor& counts, uint64_t fill_bits)
+{
+    if (!g_api.gather_fill || !plain_cuda(data) || !plain_cuda(indices) || !plain_cuda(counts)) return py::none();
+    const int64_t nb = counts.dim();
+    if (nb < 1 || indices.dim() != nb + 1 || data.dim() < nb + 1 || index_code(indices) < 0 || index_code(counts) < 0)
+        return py::none();
+    if (!on_current_device(data) || indices.get_device() != data.get_device() || counts.get_device() != data.get_device())
+        return py::none();
+    const auto st = data.scalar_type();
+    if (!(st == at::kFloat || st == at::kDouble || st == at::kHalf || st == at::kBFloat16 || st == at::kInt || st == at::kLong))
+        return py::none();
+    int64_t batch = 1;
+    for (int64_t d = 0; d < nb; ++d) {
+        if (data.size(d) != counts.size(d) || indices.size(d) != counts.size(d)) return py::none();
+        batch *= counts.size(d);
+    }
+    std::vector<int64_t> shape(indices.sizes().begin(), indices.sizes().end());
+    for (int64_t d = nb + 1; d < data.dim(); ++d) shape.push_back(data.size(d));
+    at::Tensor res = at::empty(shape, data.options());
+    if (indices.numel() == 0 || res.numel() == 0) return py::none();   // (the python path returns torch.full there)
+    const int64_t esz = (int64_t)data.element_size();
+    check_status(g_api.gather_fill(data.data_ptr(), res.data_ptr(), indices.data_ptr(), counts.data_ptr(), batch, data.size(nb),
+                                   indices.size(nb), indices.size(nb), row_elems(data, nb + 1) * esz, fill_bits, (int)esz,
+                                   index_code(indices), index_code(counts), nullptr, stream_of(data)),
+                 "forward");
+    return py::cast(res);
+}
 
 // depth-first flatten of nested list/tuple structures into tensor leaves; false = something else was found
 bool flatten(PyObject* obj, std::vector<at::Tensor>& out)
@@ -173,4 +275,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("pack_cpu", &pack_cpu, py::arg("data"), py::arg("pin") = false, py::arg("max_bytes") = 0);
     m.def("cat_leaves", &cat_leaves, py::arg("data"), py::arg("pin") = false);
     m.def("split_views", &split_views);
+    m.def("bind_native", &bind_native);
+    m.def("gather_rows", &gather_rows);
+    m.def("scatter_rows", &scatter_rows);
+    m.def("forward_gather_fill", &forward_gather_fill);
 }

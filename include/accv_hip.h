@@ -44,8 +44,8 @@ extern "C" {
 #define ACCV_HM_PLAIN_STORES 128u /* hint: plain stores for every plane.  Default: fused-clear launches store plain; in-place
                                     launches choose per plane — write-through non-temporal where the plane's objects
                                     cover >= 3/4 of its area (sum of (2r+1)^2), plain elsewhere.  Same results. */
-#define ACCV_HM_TILE_ROWS_16 32u /* hint: 128 x 32 pixel tiles (default only for fused-clear launches above 128 MB) */
-#define ACCV_HM_TILE_ROWS_8 64u  /* hint: 128 x 16 pixel tiles (default for everything else).  Same results either way. */
+#define ACCV_HM_TILE_ROWS_16 32u /* hint: 128 x 32 pixel wave tiles (half the waves, twice the registers per wave) */
+#define ACCV_HM_TILE_ROWS_8 64u  /* hint: 128 x 16 pixel wave tiles (the default).  Same results either way. */
 
 const char* accv_last_error(void);
 int accv_version(void);

@@ -281,7 +281,7 @@ def test_many_small_gpu_tensors_take_the_coalesced_gpu_to_gpu_path(monkeypatch):
     assert len(calls) == 2
 
 
-@pytest.mark.parametrize("n", [64, 528, 3000])
+@pytest.mark.parametrize("n", [64, 528, 3000, 12000])
 def test_background_mode_runs_on_the_native_orchestrator(n):
     """use_background_thread=True with nothing but small host tensors never starts a python worker: the library's own
     thread stages and enqueues (accv_mtc_stage_h2d_async), ready() polls it, results are byte exact and ordered after
@@ -294,7 +294,10 @@ def test_background_mode_runs_on_the_native_orchestrator(n):
     for _ in range(10):
         acc += 1
     h = mtc.start_copy(data, DEV, use_background_thread=True)
-    assert h._future is None and (h._job.ticket is not None or h._job.pending_views is not None)
+    assert h._future is None and h._job.pending_views is not None
+    total = sum(t.numel() * t.element_size() for d in data for t in (d["a"], d["b"][0]))
+    from accvlab.multi_tensor_copier import copier
+    assert (h._job.ticket is not None) == (total > copier._NATIVE_THREAD_MIN_BYTES)   # small jobs stage on the caller thread
     import time
     t0 = time.time()
     while not h.ready():
