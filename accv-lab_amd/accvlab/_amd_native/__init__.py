@@ -77,6 +77,7 @@ SIGNATURES = {
     # lane_helpers
     "accv_polyline_scratch_bytes": (_sz, [_ll, _i, _i]),
     "accv_polyline_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "accv_polyline_sample_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i]),
     "accv_polyline_sample_boxes": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 # not in the public header and not in the shipped library: the knob setter of the A/B build (make -C csrc tune)
@@ -97,7 +98,7 @@ if os.environ.get("ACCV_NO_FASTCALL") == "1":
 _INT_CLASS = (_vp, _i, _u, _sz, _i64, _ll, _u64)
 # entry points that BLOCK (wait for a native job, run a long host memcpy): they stay on ctypes, which drops the
 # interpreter lock for the duration of the call — the trampoline keeps it
-_BLOCKING = {"accv_mtc_async_wait", "accv_mtc_stage_h2d", "accv_mtc_pack_host"}
+_BLOCKING = {"accv_mtc_async_wait", "accv_mtc_stage_h2d", "accv_mtc_pack_host", "accv_polyline_sample_host"}
 
 
 def _fast_entry(fn, res, args):

@@ -92,6 +92,35 @@ def _gpu(points, distances, p_sizes, d_sizes, relative, want_points, want_length
     return out_p, out_l
 
 
+def _host(points, distances, p_sizes, d_sizes, relative, want_points, want_lengths):
+    """CPU tensors: the native host implementation behind the C-ABI (accv_polyline_sample_host — double accumulation and
+    threading as the reference's polyline_cpu.cpp:28-132).  float32 / float64; the torch formulations below
+    (_cpu_interpolate / _cpu_lengths) remain as its cross-check in the tests."""
+    lib = _nat.lib()
+    b, pmax, dims = points.shape
+    qmax = distances.shape[1] if distances is not None else 0
+    out_p = torch.empty((b, qmax, dims), dtype=points.dtype) if want_points else None
+    out_l = torch.empty((b,), dtype=points.dtype) if want_lengths else None
+    if b == 0:
+        return out_p, out_l
+    points = points.contiguous()
+    distances = distances.contiguous() if distances is not None else None
+    c64 = 0
+    present = [t for t in (p_sizes, d_sizes) if t is not None]
+    if present:
+        wide = any(t.dtype == torch.int64 for t in present)
+        want = torch.int64 if wide else torch.int32
+        c64 = 1 if wide else 0
+        p_sizes = p_sizes.to(want).contiguous() if p_sizes is not None else None
+        d_sizes = d_sizes.to(want).contiguous() if d_sizes is not None else None
+    _nat.check(lib.accv_polyline_sample_host(
+        points.data_ptr(), distances.data_ptr() if distances is not None else None,
+        p_sizes.data_ptr() if p_sizes is not None else None, d_sizes.data_ptr() if d_sizes is not None else None,
+        out_p.data_ptr() if out_p is not None and out_p.numel() else None, out_l.data_ptr() if out_l is not None else None,
+        b, pmax, qmax, dims, _DTYPE_CODE[points.dtype], c64, int(bool(relative)), 0), "polyline (host)")
+    return out_p, out_l
+
+
 def _cpu_accum(points, p_sizes):
     """float64 accumulated distances [B, P] with +inf behind the valid points, and total lengths."""
     b, pmax, _ = points.shape
@@ -166,7 +195,7 @@ def interpolate(points: torch.Tensor, distances: torch.Tensor, *, relative: bool
         raise RuntimeError("points and distances must be on the same device")
     if points.is_cuda:
         return _gpu(points, distances, None, None, relative, True, False)[0]
-    return _cpu_interpolate(points, distances, None, None, relative)
+    return _host(points, distances, None, None, relative, True, False)[0]
 
 
 def lengths(points: torch.Tensor) -> torch.Tensor:
@@ -176,7 +205,7 @@ def lengths(points: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("points must have shape (batch, num_points, num_dims)")
     if points.is_cuda:
         return _gpu(points, None, None, None, False, False, True)[1]
-    return _cpu_lengths(points, None)
+    return _host(points, None, None, None, False, False, True)[1]
 
 
 def _check_var(points, sizes, name):
@@ -216,7 +245,7 @@ def interpolate_var_size_batch(points, distances, *, relative: bool = False):
     if pt.is_cuda:
         res = _gpu(pt, dt, ps, ds, relative, True, False)[0]
     else:
-        res = _cpu_interpolate(pt, dt, ps, ds, relative)
+        res = _host(pt, dt, ps, ds, relative, True, False)[0]
     return distances.create_with_sample_sizes_like_self(res)
 
 
@@ -232,4 +261,4 @@ def lengths_var_size_batch(points) -> torch.Tensor:
     _check_size_values([(ps, pt.size(1), "points.sample_sizes")])
     if pt.is_cuda:
         return _gpu(pt, None, ps, None, False, False, True)[1]
-    return _cpu_lengths(pt, ps)
+    return _host(pt, None, ps, None, False, False, True)[1]

@@ -15,6 +15,11 @@
 // scratch row instead (same code path, pointer swap).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+#include <limits>
+#include <thread>
+#include <vector>
+
 #include <algorithm>
 #include <cstdint>
 #include <limits>
@@ -309,4 +314,127 @@ int accv_polyline_sample(const void* points, const void* distances, const void* 
                                       max_points, max_distances, num_dims, dtype, counts_i64, relative, scratch,
                                       scratch_bytes, stream);
 }
+}
+
+// ---------------------------------------------------------------- host path (CPU tensors)
+// The reference's CPU implementation (packages/lane_helpers/ext_impl/polyline/src/polyline_cpu.cpp:28-132) accumulates in
+// at::acc_type<dtype, false> = double for float and double inputs and runs at::parallel_for over the polylines; this is its
+// counterpart for host memory: double accumulation, the same search / clamping / zero-length-segment / empty-polyline
+// rules as the kernel above (polyline_common.cuh:58-163), polylines split over std::threads when there is enough work.
+namespace {
+
+template <typename T>
+void sample_one_host(const T* pts, const T* dist, int n, int q, int dims, bool relative, T* out, T* out_len,
+                     std::vector<double>& acc)
+{
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    if (out_len) *out_len = (T)(n == 0 ? nan : 0.0);
+    if (n == 0) {
+        if (out)
+            for (int i = 0; i < q * dims; ++i) out[i] = (T)nan;
+        return;
+    }
+    acc.resize((size_t)n);
+    acc[0] = 0.0;
+    for (int i = 1; i < n; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < dims; ++k) {
+            const double d = (double)pts[(size_t)(i - 1) * dims + k] - (double)pts[(size_t)i * dims + k];
+            s += d * d;
+        }
+        acc[(size_t)i] = acc[(size_t)i - 1] + std::sqrt(s);
+    }
+    const double total = acc[(size_t)n - 1];
+    if (out_len) *out_len = (T)total;
+    if (!out) return;
+    const double eps = std::numeric_limits<double>::epsilon();
+    for (int j = 0; j < q; ++j) {
+        double d = (double)dist[j];
+        if (relative) d *= total;
+        // index of the last accumulated distance <= d (-1: before the start, n-1: at / beyond the end)
+        int idx;
+        if (acc[0] > d) {
+            idx = -1;
+        } else if (acc[(size_t)n - 1] < d) {
+            idx = n - 1;
+        } else {
+            int lo = 0, hi = n - 1;
+            while (hi - lo > 1) {
+                const int c = (lo + hi) >> 1;
+                if (acc[(size_t)c] < d)
+                    lo = c;
+                else if (acc[(size_t)c] > d)
+                    hi = c;
+                else
+                    lo = hi = c;
+            }
+            idx = lo;
+        }
+        T* o = out + (size_t)j * dims;
+        if (idx >= 0 && idx < n - 1) {
+            const double seg = acc[(size_t)idx + 1] - acc[(size_t)idx];
+            if (seg >= eps) {
+                const double w0 = (acc[(size_t)idx + 1] - d) / seg, w1 = (d - acc[(size_t)idx]) / seg;
+                for (int k = 0; k < dims; ++k)
+                    o[k] = (T)((double)pts[(size_t)idx * dims + k] * w0 + (double)pts[(size_t)(idx + 1) * dims + k] * w1);
+            } else {
+                for (int k = 0; k < dims; ++k) o[k] = pts[(size_t)idx * dims + k];   // zero-length segment: its lower point
+            }
+        } else {
+            const int e = idx < 0 ? 0 : n - 1;                                        // clamped to an end point
+            for (int k = 0; k < dims; ++k) o[k] = pts[(size_t)e * dims + k];
+        }
+    }
+}
+
+template <typename T>
+void sample_host(const void* points, const void* distances, const void* pc, const void* dc, void* out_points, void* out_lengths,
+                 long long batch, int P, int Q, int D, int counts_i64, int relative, int threads)
+{
+    auto count_of = [&](const void* c, long long i, int cap) {
+        if (!c) return cap;
+        const long long v = counts_i64 ? static_cast<const long long*>(c)[i] : (long long)static_cast<const int*>(c)[i];
+        return (int)std::max(0ll, std::min(v, (long long)cap));
+    };
+    auto run = [&](long long lo, long long hi) {
+        std::vector<double> acc;
+        for (long long i = lo; i < hi; ++i)
+            sample_one_host<T>(static_cast<const T*>(points) + (size_t)i * P * D,
+                               distances ? static_cast<const T*>(distances) + (size_t)i * Q : nullptr, count_of(pc, i, P),
+                               out_points ? count_of(dc, i, Q) : 0, D, relative != 0,
+                               out_points ? static_cast<T*>(out_points) + (size_t)i * Q * D : nullptr,
+                               out_lengths ? static_cast<T*>(out_lengths) + i : nullptr, acc);
+    };
+    const long long work = batch * ((long long)P + Q) * std::max(1, D);
+    int t = (int)std::min<long long>(std::max(1, threads), std::min<long long>(batch, work / 65536 + 1));
+    if (t <= 1) {
+        run(0, batch);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int k = 0; k < t; ++k) pool.emplace_back(run, batch * k / t, batch * (k + 1) / t);
+    for (auto& th : pool) th.join();
+}
+
+}  // namespace
+
+extern "C" int accv_polyline_sample_host(const void* points, const void* distances, const void* point_counts,
+                                         const void* dist_counts, void* out_points, void* out_lengths, long long batch,
+                                         int max_points, int max_distances, int num_dims, int dtype, int counts_i64,
+                                         int relative, int threads)
+{
+    if (batch < 0 || max_points < 0 || max_distances < 0 || num_dims < 0)
+        return accv::fail(ACCV_EINVAL, "polyline (host): negative extent");
+    if (dtype != 0 && dtype != 1) return accv::fail(ACCV_EINVAL, "polyline (host): float32 / float64 only, got dtype code %d", dtype);
+    if (batch == 0 || (!out_points && !out_lengths)) return ACCV_OK;
+    if (max_points > 0 && num_dims > 0 && !points) return accv::fail(ACCV_EINVAL, "polyline (host): null points");
+    if (out_points && max_distances > 0 && !distances) return accv::fail(ACCV_EINVAL, "polyline (host): null distances");
+    if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (dtype == 0)
+        sample_host<float>(points, distances, point_counts, dist_counts, out_points, out_lengths, batch, max_points,
+                           max_distances, num_dims, counts_i64, relative, threads);
+    else
+        sample_host<double>(points, distances, point_counts, dist_counts, out_points, out_lengths, batch, max_points,
+                            max_distances, num_dims, counts_i64, relative, threads);
+    return ACCV_OK;
 }

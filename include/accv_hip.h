@@ -285,6 +285,13 @@ int accv_polyline_sample(const void* points, const void* distances, const void* 
                          int num_dims, int dtype, int counts_i64, int relative, void* scratch, size_t scratch_bytes,
                          void* stream);
 
+/* The same operation on HOST memory (CPU tensors): counterpart of the reference's CPU implementation
+ * (ext_impl/polyline/src/polyline_cpu.cpp:28-132): float32 / float64 only (dtype 0 / 1), double accumulation
+ * (at::acc_type<dtype, false>), polylines split over up to `threads` host threads (0 = automatic).  No HIP call. */
+int accv_polyline_sample_host(const void* points, const void* distances, const void* point_counts, const void* dist_counts,
+                              void* out_points, void* out_lengths, long long batch, int max_points, int max_distances,
+                              int num_dims, int dtype, int counts_i64, int relative, int threads);
+
 /* The same sampler with one more output (float32 samples of 2-D points only): out_group_boxes f32[batch, ceil(Q/64), 4] =
  * (xmin, ymin, xmax, ymax) of every 64 consecutive samples of a polyline, NaN samples ignored, (+inf, +inf, -inf, -inf) for
  * a group without valid samples — what accv_draw_points_multiscale_f32 culls by (ACCV_HM_GROUP_BOXES_GIVEN saves its own

@@ -67,6 +67,9 @@ def main():
     wrap(copier, "_make_leaf_set", "tree build (walk)")
     wrap(copier, "_run", "_run total")
     wrap(copier, "_plan", "plan (numpy prep + C-ABI)")
+    wrap(copier, "_prepare_packed_h2d", "prepare packed (plan + chunks + staging blocks + ordering)")
+    wrap(copier, "_start_native_h2d", "native background submit (prepare + async stage)")
+    wrap(copier, "_rebuild_without_gc", "rebuild (gc paused)")
     tree_cls = copier._host.Tree if copier._host is not None else copier._PyLeafSet
     for m in ("classify", "make_packed_views", "rebuild"):
         wrap(tree_cls, m, f"tree.{m}")
@@ -76,15 +79,20 @@ def main():
     acc.clear()
     t_total = 0.0
     t_get = 0.0
+    t_free = 0.0
     for _ in range(a.iters):
         t0 = time.perf_counter()
         h = copier.start_copy(tree, dev, use_background_thread=a.background)
         t1 = time.perf_counter()
-        h.get()
+        res = h.get()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
+        del res, h                       # a timing loop that discards its result pays for freeing 10 k tensors each time
+        t3 = time.perf_counter()
         t_total += t2 - t0
         t_get += t2 - t1
+        t_free += t3 - t2
+    acc["free the previous result (del)"] = t_free
     out = {k: round(v / a.iters * 1e3, 4) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])}
     out["start_copy+get total ms"] = round(t_total / a.iters * 1e3, 4)
     out["get() (wait + rebuild) ms"] = round(t_get / a.iters * 1e3, 4)

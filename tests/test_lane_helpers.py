@@ -149,3 +149,37 @@ def test_gpu_dtypes_long_polylines_and_edge_cases():
     assert poly.interpolate(torch.empty((2, 0, 3), device=dev), torch.empty((2, 0), device=dev)).shape == (2, 0, 3)
     assert bool(torch.isnan(poly.lengths(torch.empty((2, 0, 3), device=dev))).all())
     assert poly.lengths(torch.ones((2, 1, 3), device=dev)).tolist() == [0.0, 0.0]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("relative", [False, True])
+def test_native_host_path_matches_the_torch_formulation_and_the_oracle(dtype, relative):
+    """CPU tensors run accv_polyline_sample_host (C++, double accumulation — the reference's polyline_cpu.cpp:28-132);
+    cross-checked against the float64 torch formulation kept in ops.py and, per polyline, against oracle/lane.py, on
+    ragged batches with empty polylines, repeated points (zero-length segments) and queries outside [0, length]."""
+    from accvlab.lane_helpers.polyline import ops
+    from oracle import lane as oracle_lane
+
+    g = torch.Generator().manual_seed(5)
+    b, p, q, d = 300, 17, 23, 3
+    pts = torch.cumsum(torch.rand(b, p, d, generator=g, dtype=torch.float64), 1).to(dtype)
+    pts[:, 5] = pts[:, 4]                                          # a zero-length segment in every polyline
+    n = torch.randint(0, p + 1, (b,), generator=g)
+    n[:3] = torch.tensor([0, 1, p])
+    m = torch.randint(0, q + 1, (b,), generator=g)
+    dist = (torch.rand(b, q, generator=g, dtype=torch.float64) * (1.4 if relative else 12.0) - (0.2 if relative else 1.0)).to(dtype)
+    got, _ = ops._host(pts, dist, n, m, relative, True, False)
+    ref = ops._cpu_interpolate(pts, dist, n, m, relative)
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    for i in range(b):
+        k = int(m[i])
+        a, r = got[i, :k].double(), ref[i, :k].double()
+        assert torch.equal(torch.isnan(a), torch.isnan(r))
+        assert float((torch.nan_to_num(a) - torch.nan_to_num(r)).abs().max() if k else 0.0) <= tol * 20
+        if i < 40:
+            want = oracle_lane.sample(pts[i, :int(n[i])].numpy(), dist[i, :k].numpy(), relative=relative)
+            assert np.allclose(np.nan_to_num(a.numpy()), np.nan_to_num(want), atol=tol * 20, rtol=0)
+    _, lens = ops._host(pts, None, n, None, False, False, True)
+    ref_l = ops._cpu_lengths(pts, n)
+    assert torch.equal(torch.isnan(lens), torch.isnan(ref_l)) and float(torch.nan_to_num(lens - ref_l).abs().max()) <= tol * 20
+    assert bool(torch.isnan(lens[0])) and float(lens[1]) == 0.0     # empty -> NaN, single point -> 0
