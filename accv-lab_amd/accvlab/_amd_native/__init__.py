@@ -56,6 +56,8 @@ SIGNATURES = {
     "accv_ragged_pad_fill": (_i, [_vp, _vp, _ll, _ll, _ll, _u64, _i, _i, _vp]),
     "accv_ragged_accumulate": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _i, _i, _vp, _vp]),
     "accv_ragged_mask_to_indices": (_i, [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp]),
+    "accv_ragged_mask_to_indices_workspace_bytes": (_sz, [_ll, _ll]),
+    "accv_ragged_mask_to_indices_ws": (_i, [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp, _sz, _vp]),
     "accv_ragged_pack": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _i, _vp]),
     "accv_matched_pair_reduce_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _f, _i, _i, _vp, _vp]),
     "accv_matched_pair_reduce_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _f, _i, _i,

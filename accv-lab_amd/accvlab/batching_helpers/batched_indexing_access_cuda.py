@@ -421,9 +421,17 @@ def mask_to_indices(mask: torch.Tensor, valid_counts: Optional[torch.Tensor] = N
         valid_counts = valid_counts.contiguous()
         vc_ptr, vc64 = valid_counts.data_ptr(), _index_dtype(valid_counts, "valid_counts")
     if b > 0:
+        lib = _nat.lib()
         with _nat.device_guard(m.device):
-            _call(_nat.lib().accv_ragged_mask_to_indices(m.data_ptr(), vc_ptr, vc64, b, w, idx.data_ptr(),
-                                                         sizes.data_ptr(), _stream(m)), "mask_to_indices")
+            # few, very wide rows take the segmented two-pass kernels, which need a few KB of workspace
+            ws_bytes = lib.accv_ragged_mask_to_indices_workspace_bytes(b, w) if w >= 8192 else 0
+            if ws_bytes:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=m.device)
+                _call(lib.accv_ragged_mask_to_indices_ws(m.data_ptr(), vc_ptr, vc64, b, w, idx.data_ptr(), sizes.data_ptr(),
+                                                         ws.data_ptr(), ws_bytes, _stream(m)), "mask_to_indices")
+            else:
+                _call(lib.accv_ragged_mask_to_indices(m.data_ptr(), vc_ptr, vc64, b, w, idx.data_ptr(),
+                                                      sizes.data_ptr(), _stream(m)), "mask_to_indices")
     return idx, sizes
 
 

@@ -292,6 +292,109 @@ __global__ __launch_bounds__(256) void mask_to_indices_kernel(const uint8_t* __r
     if (lane == 0) out_sizes[row] = offset;
 }
 
+// ---- few, very wide rows (a dense anchor mask of a small batch): a row is cut into segments of kSeg mask bytes, one
+// workgroup per (segment, row) — 8 rows of 65 536 keep 128 workgroups busy instead of 8.  Pass 1 counts the hits per
+// segment into a small workspace; pass 2 turns the counts of its row into its base offset (a wave reduction) and writes
+// its indices and its share of the zero tail.  Every thread owns 16 consecutive mask bytes (one 16-byte load when the row
+// is 16-byte aligned): count, exclusive scan over the 256 threads, then it writes its <= 16 indices in order.
+constexpr int kSeg = 4096;
+
+__device__ __forceinline__ unsigned nonzero_bytes16(const uint8_t* m, long long j0, long long limit, bool vec)
+{
+    // bit k set <=> byte j0 + k is a hit (non-zero and below `limit`)
+    unsigned bits = 0;
+    if (vec && j0 + 16 <= limit) {
+        const uint4 v = *reinterpret_cast<const uint4*>(m + j0);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bits |= (((w[q] >> (8 * b)) & 0xffu) ? 1u : 0u) << (4 * q + b);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (j0 + k < limit && m[j0 + k] != 0) bits |= 1u << k;
+    }
+    return bits;
+}
+
+__global__ __launch_bounds__(256) void mask_seg_count_kernel(const uint8_t* __restrict__ mask, const void* __restrict__ valid,
+                                                             int valid_i64, long long width, int segs, int vec,
+                                                             int* __restrict__ seg_counts)
+{
+    __shared__ int s_w[4];
+    const long long row = blockIdx.y;
+    long long limit = width;
+    if (valid) limit = max(0ll, min(width, load_int(valid, row, valid_i64)));
+    const long long j0 = (long long)blockIdx.x * kSeg + (long long)threadIdx.x * 16;
+    int c = j0 < limit ? __popc(nonzero_bytes16(mask + row * width, j0, limit, vec != 0)) : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_counts[row * segs + blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void mask_seg_write_kernel(const uint8_t* __restrict__ mask, const void* __restrict__ valid,
+                                                             int valid_i64, long long width, int segs, int vec,
+                                                             const int* __restrict__ seg_counts, long long* __restrict__ out_idx,
+                                                             long long* __restrict__ out_sizes)
+{
+    __shared__ long long s_base, s_total;
+    __shared__ int s_w[4];
+    const long long row = blockIdx.y;
+    const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long limit = width;
+    if (valid) limit = max(0ll, min(width, load_int(valid, row, valid_i64)));
+    if (wave == 0) {  // offsets of this row's segments: hits before this one, and the row total
+        long long before = 0, total = 0;
+        for (int s0 = 0; s0 < segs; s0 += 64) {
+            const int sidx = s0 + lane;
+            const long long c = sidx < segs ? seg_counts[row * segs + sidx] : 0;
+            long long b = sidx < seg ? c : 0, t = c;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                b += __shfl_xor(b, d);
+                t += __shfl_xor(t, d);
+            }
+            before += b;
+            total += t;
+        }
+        if (lane == 0) {
+            s_base = before;
+            s_total = total;
+        }
+    }
+    const long long j0 = (long long)seg * kSeg + (long long)tid * 16;
+    const unsigned bits = j0 < limit ? nonzero_bytes16(mask + row * width, j0, limit, vec != 0) : 0u;
+    const int c = __popc(bits);
+    int incl = c;  // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int wave_before = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) wave_before += s_w[w];
+    long long* o = out_idx + row * width;
+    long long pos = s_base + wave_before + (incl - c);
+    unsigned b = bits;
+    while (b) {  // this thread's hits, in order
+        const int k = __builtin_ctz(b);
+        b &= b - 1;
+        o[pos++] = j0 + k;
+    }
+    // zero tail of the row: positions [total, width) that fall into this segment's position range
+    const long long total = s_total;
+    const long long z0 = max(total, (long long)seg * kSeg), z1 = min(width, (long long)(seg + 1) * kSeg);
+    for (long long j = z0 + tid; j < z1; j += 256) o[j] = 0;
+    if (seg == 0 && tid == 0) out_sizes[row] = total;
+}
+
 // ---- flat -> padded pack: dst[i, j, :] = flat[offsets[i] + j, :] (j < sizes[i]); padding gets `pattern`
 // wide rows: one WORKGROUP of NW waves per row, NW*64 mask bytes per step; the waves' hit counts meet in LDS (double
 // buffered: one barrier per step) so that the order-preserving offsets stay exact
@@ -547,8 +650,18 @@ int accv_ragged_accumulate(const void* src, void* dst, const void* src_indices_o
     return accv::check_launch("ragged_accumulate");
 }
 
-int accv_ragged_mask_to_indices(const void* mask_u8, const void* valid_counts_or_null, int valid_i64, long long batch,
-                                long long width, long long* out_indices, long long* out_sizes, void* stream_)
+size_t accv_ragged_mask_to_indices_workspace_bytes(long long batch, long long width)
+{
+    // the segmented two-pass path pays for few, very wide rows; everything else needs no workspace
+    if (batch <= 0 || width < 2 * kSeg || batch > 1024) return 0;
+    const long long segs = (width + kSeg - 1) / kSeg;
+    if (segs > 65535 || batch > 65535) return 0;
+    return (size_t)batch * (size_t)segs * sizeof(int);
+}
+
+int accv_ragged_mask_to_indices_ws(const void* mask_u8, const void* valid_counts_or_null, int valid_i64, long long batch,
+                                   long long width, long long* out_indices, long long* out_sizes, void* workspace,
+                                   size_t workspace_bytes, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (batch < 0 || width < 0) return accv::fail(ACCV_EINVAL, "ragged_mask_to_indices: negative extent");
@@ -556,6 +669,17 @@ int accv_ragged_mask_to_indices(const void* mask_u8, const void* valid_counts_or
     if (!out_sizes || (width > 0 && (!mask_u8 || !out_indices)))
         return accv::fail(ACCV_EINVAL, "ragged_mask_to_indices: null pointer");
     const uint8_t* m = static_cast<const uint8_t*>(mask_u8);
+    const size_t need = accv_ragged_mask_to_indices_workspace_bytes(batch, width);
+    if (need > 0 && workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 3u) == 0) {
+        const int segs = (int)((width + kSeg - 1) / kSeg);
+        const int vec = ((reinterpret_cast<uintptr_t>(m) & 15u) == 0 && width % 16 == 0) ? 1 : 0;
+        const dim3 grid((unsigned)segs, (unsigned)batch), block(256);
+        int* counts = static_cast<int*>(workspace);
+        hipLaunchKernelGGL(mask_seg_count_kernel, grid, block, 0, stream, m, valid_counts_or_null, valid_i64, width, segs, vec, counts);
+        hipLaunchKernelGGL(mask_seg_write_kernel, grid, block, 0, stream, m, valid_counts_or_null, valid_i64, width, segs, vec,
+                           counts, out_indices, out_sizes);
+        return accv::check_launch("ragged_mask_to_indices (segmented)");
+    }
     if (width > 512 && batch <= 0x7fffffff) {  // wide rows: a workgroup per row (16x / 4x the lanes of a wave per row)
         if (width > 4096)
             hipLaunchKernelGGL((mask_to_indices_block_kernel<16>), dim3((unsigned)batch), dim3(1024), 0, stream, m,
@@ -569,6 +693,13 @@ int accv_ragged_mask_to_indices(const void* mask_u8, const void* valid_counts_or
     hipLaunchKernelGGL(mask_to_indices_kernel, dim3(grid), dim3(256), 0, stream, m, valid_counts_or_null, valid_i64, batch,
                        width, out_indices, out_sizes);
     return accv::check_launch("ragged_mask_to_indices");
+}
+
+int accv_ragged_mask_to_indices(const void* mask_u8, const void* valid_counts_or_null, int valid_i64, long long batch,
+                                long long width, long long* out_indices, long long* out_sizes, void* stream_)
+{
+    return accv_ragged_mask_to_indices_ws(mask_u8, valid_counts_or_null, valid_i64, batch, width, out_indices, out_sizes, nullptr,
+                                          0, stream_);
 }
 
 int accv_ragged_pack(const void* flat, void* padded, const long long* offsets, const long long* sizes, long long batch,

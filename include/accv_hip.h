@@ -184,6 +184,15 @@ int accv_ragged_accumulate(const void* src, void* dst, const void* src_indices_o
  * looked at when valid_counts is given.  out_indices is [batch, width]. */
 int accv_ragged_mask_to_indices(const void* mask_u8, const void* valid_counts_or_null, int valid_i64, long long batch,
                                 long long width, long long* out_indices, long long* out_sizes, void* stream);
+/* The same with a caller-provided workspace of accv_ragged_mask_to_indices_workspace_bytes(batch, width) bytes (0 = not
+ * needed): FEW, VERY WIDE rows (a dense anchor mask of a small batch) are cut into 4096-byte segments handled by one
+ * workgroup each (count pass + write pass) instead of one workgroup per row.  Same results; without (enough) workspace
+ * the one-workgroup-per-row kernels run. */
+size_t accv_ragged_mask_to_indices_workspace_bytes(long long batch, long long width);
+int accv_ragged_mask_to_indices_ws(const void* mask_u8, const void* valid_counts_or_null, int valid_i64, long long batch,
+                                   long long width, long long* out_indices, long long* out_sizes, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
 
 /* F3 — matched gather + element-wise loss + masked per-sample sum in ONE launch.  The caller pattern of
  * packages/batching_helpers/example/loss_computation.py:37-43 (batched_indexing_access of ground truth and prediction

@@ -82,6 +82,12 @@ def main():
                       "mask_to_indices_GBps_of_mask_plus_index_bytes": (mask.numel() + mask.numel() * 8) / t_m2i / 1e9,
                       "mask_to_indices_us": t_m2i * 1e6,
                       "accumulate_scatter_GBps": acc_bytes / t_acc / 1e9, "accumulate_us": t_acc * 1e6}))
+    # few, very wide rows (dense anchor masks of a small batch): segmented two-pass kernels
+    for (b2, w2) in ((8, 65536), (2, 262144), (64, 65536)):
+        mask2 = (torch.rand(b2, w2, generator=g) < 0.3).to(dev)
+        t2 = timeit(lambda: ext.mask_to_indices(mask2))
+        print(json.dumps({"mask_to_indices": {"batch": b2, "width": w2}, "us": t2 * 1e6,
+                          "GBps_of_mask_plus_index_bytes": (mask2.numel() * 9) / t2 / 1e9}))
     for line in out_lines:
         print(json.dumps(line))
 

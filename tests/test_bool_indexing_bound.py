@@ -76,10 +76,12 @@ def test_bound_gpu_and_graph_capture():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("b,m", [(5, 64), (3, 513), (7, 900), (2, 4096), (3, 4097), (2, 70001), (1, 1)])
+@pytest.mark.parametrize("b,m", [(5, 64), (3, 513), (7, 900), (2, 4096), (3, 4097), (2, 70001), (1, 1), (2, 8192), (3, 20000),
+                                 (8, 65536), (1, 8191)])
 @pytest.mark.parametrize("ragged", [False, True])
 def test_mask_to_indices_all_kernel_variants(b, m, ragged):
-    # widths <= 512: a wave per row; <= 4096: 4 waves per row; above: 16 waves per row — all order preserving
+    # widths <= 512: a wave per row; <= 4096: 4 waves per row; above: 16 waves per row; >= 8192 with few rows: 4096-byte
+    # segments, one workgroup each, two passes (16-byte loads when the row is aligned, byte loads otherwise) — all order preserving
     from accvlab.batching_helpers import batched_indexing_access_cuda as ext
 
     dev = torch.device("cuda", 0)
