@@ -131,10 +131,18 @@ __device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, Tile
     } else {  // linear block index (more than 65535 planes or tile rows)
         const long long tile = linear_group * WPG + wave;
         if (tile >= p.n_tiles) return false;  // whole wave exits; waves never synchronise with each other
-        tx = (int)(tile % p.tiles_x);
-        const long long t2 = tile / p.tiles_x;
-        ty = (int)(t2 % p.tiles_y);
-        t.plane = t2 / p.tiles_y;
+        if (p.n_tiles <= 0x7fffffffll) {      // 32-bit divisions (a 64-bit one costs ~60 instructions, and there are three)
+            const unsigned t32 = (unsigned)tile, t2 = t32 / (unsigned)p.tiles_x;
+            tx = (int)(t32 - t2 * (unsigned)p.tiles_x);
+            const unsigned pl = t2 / (unsigned)p.tiles_y;
+            ty = (int)(t2 - pl * (unsigned)p.tiles_y);
+            t.plane = pl;
+        } else {
+            tx = (int)(tile % p.tiles_x);
+            const long long t2 = tile / p.tiles_x;
+            ty = (int)(t2 % p.tiles_y);
+            t.plane = t2 / p.tiles_y;
+        }
     }
     t.tx0 = tx * TW;
     t.ty0 = ty * TH;
@@ -443,26 +451,40 @@ __global__ __launch_bounds__(64) void splat_multi_kernel(const MultiParams mp)
 // atomic (ds_max_f32) per box pixel, four hits in flight per wave.  Correct for any radius, but only faster below
 // ~15x15 boxes; the host selects it on the caller's ACCV_HM_SMALL_RADII hint.  Same culling, same store path, same
 // clear / in-place semantics.  SRC = 2 (splat_points_multi_kernel) reads float sample points and culls in two levels.
-template <bool CLEAR, int SM, int SRC>
+// NW waves share one tile (NW = 4 for the lane raster): a tile crossed by several lanes at a coarse scale has 6-8 sample
+// groups to walk, a serial chain of ~2.5 us per group for ONE wave (24 us for the 576 tiles of a stride-16 map, as long
+// as the 8704 tiles of the stride-4 map take) — with four waves the groups of a tile are dealt round-robin over the waves
+// (the LDS float-max atomics commute, also across waves), and an empty tile is stored by four waves with two store
+// instructions each instead of one wave with eight.
+template <bool CLEAR, int SM, int SRC, int NW = 1>
 __device__ __forceinline__ void small_body(const SplatParams& p, long long linear_group)
 {
     constexpr int TW = 128, TH = 16;
-    __shared__ Hit s_hit[kCand];
+    constexpr int RPW = TH / NW / 2;  // rows per half-wave in the init / read-back passes
+    static_assert(TH % (2 * NW) == 0, "rows must split evenly over the half-waves of the workgroup");
+    __shared__ Hit s_hit[NW][kCand];
     __shared__ __attribute__((aligned(16))) float s_tile[TH][TW];
+    __shared__ int s_touched;
 
     const int lane = threadIdx.x & 63;
+    const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
     TileCtx t;
-    if (!locate_tile<TW, TH, 1>(p, 0, t, linear_group)) return;
+    if (!locate_tile<TW, TH, 1>(p, 0, t, linear_group)) return;  // uniform over the workgroup
     const int sub = lane >> 5, col0 = t.tx0 + (lane & 31) * 4;
+    const int row0 = wave * (TH / NW) + sub * RPW;               // first of this half-wave's rows
 
     // "untouched" is -inf in the LDS tile (fused-clear mode starts from 0 = the cleared map)
     const float init = CLEAR ? 0.0f : -__builtin_inff();
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        *reinterpret_cast<vfloat4*>(&s_tile[sub * 8 + i][(lane & 31) * 4]) = vfloat4{init, init, init, init};
-
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile initialised before the first atomic
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = 0; i < RPW; ++i)
+        *reinterpret_cast<vfloat4*>(&s_tile[row0 + i][(lane & 31) * 4]) = vfloat4{init, init, init, init};
+    if constexpr (NW > 1) {
+        if (threadIdx.x == 0) s_touched = 0;
+        __syncthreads();  // tile initialised by all waves before the first atomic of any
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile initialised before the first atomic
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 
     int total_hits = 0;
     // one cull round over the 64 candidates [sub_base, sub_base + 64): compaction, then the hits' boxes are walked
@@ -470,7 +492,7 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         const unsigned long long m = cull_test(t, sub_base, lane, cand);
         const int nh = __popcll(m);
         if (nh == 0) return;
-        if ((m >> lane) & 1ull) s_hit[__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, cand.x, cand.y, cand.r);
+        if ((m >> lane) & 1ull) s_hit[wave][__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, cand.x, cand.y, cand.r);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // four hits at a time, 16 lanes per hit walking its box.  Pixel updates are LDS float-max atomics
@@ -480,7 +502,7 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         for (int h0 = 0; h0 < nh; h0 += 4) {
             const int h = h0 + grp;
             if (h >= nh) continue;
-            const Hit hh = s_hit[h];
+            const Hit hh = s_hit[wave][h];
             const int xlo = hh.box & 255u, xhi = (hh.box >> 8) & 255u, ylo = (hh.box >> 16) & 255u, yhi = hh.box >> 24;
             const int w = xhi - xlo, area = w * (yhi - ylo);  // 0 for an empty box
             const float inv_w = 1.0f / (float)max(w, 1);
@@ -491,7 +513,8 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
                 const int px = q - py * w;
                 const float dx = (float)(t.tx0 + xlo + px - hh.x), dy = (float)(t.ty0 + ylo + py - hh.y);
                 const float v = p.k * raw_exp2(-(dx * dx + dy * dy) * hh.c2);
-                __hip_atomic_fetch_max(&s_tile[ylo + py][xlo + px], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_max(&s_tile[ylo + py][xlo + px], v, __ATOMIC_RELAXED,
+                                       NW > 1 ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
         // the next round overwrites the hit list: order it behind this round's reads
@@ -520,6 +543,13 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
                 }
             }
             unsigned long long mg = __ballot(ghit);
+            if constexpr (NW > 1) {  // every wave found the same groups; this one walks the (k * NW + wave)-th of them
+                unsigned long long mine = 0;
+                int k = 0;
+                for (unsigned long long rest = mg; rest; rest &= rest - 1, ++k)
+                    if (k % NW == wave) mine |= rest & (~rest + 1ull);
+                mg = mine;
+            }
             while (mg) {  // wave-uniform; the candidates of up to four groups are fetched together (one round trip)
                 constexpr int kFetch = 4;
                 int sub_base[kFetch];
@@ -559,16 +589,22 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         }
     }
 
-    if (!CLEAR && total_hits == 0) return;  // in-place: untouched tile costs no HBM traffic
+    if constexpr (NW > 1) {
+        if (total_hits != 0 && lane == 0) s_touched = 1;
+        __syncthreads();  // all atomics of all waves landed before the tile is read back
+        if (!CLEAR && s_touched == 0) return;  // in-place: untouched tile costs no HBM traffic
+    } else {
+        if (!CLEAR && total_hits == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // all atomics landed before the tile is read back
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     if (col0 >= p.W) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // all atomics landed before the tile is read back
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float* plane_ptr = p.hm + (size_t)t.plane * (size_t)p.H * (size_t)p.W;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = t.ty0 + sub * 8 + i;
+    for (int i = 0; i < RPW; ++i) {
+        const int row = t.ty0 + row0 + i;
         if (row >= p.H) break;
-        vfloat4 out = *reinterpret_cast<const vfloat4*>(&s_tile[sub * 8 + i][(lane & 31) * 4]);
+        vfloat4 out = *reinterpret_cast<const vfloat4*>(&s_tile[row0 + i][(lane & 31) * 4]);
         vfloat4* dst = reinterpret_cast<vfloat4*>(plane_ptr + (size_t)row * p.W + col0);
         if constexpr (!CLEAR) {
             const vfloat4 old = *dst;
@@ -594,12 +630,13 @@ __global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
 }
 
 // lane rasters of all scales in one launch: float sample points, two-level cull (SRC = 2), scale from the tile prefix
+constexpr int kPointWaves = 4;  // waves per tile of the lane raster
 template <bool CLEAR, int SM>
-__global__ __launch_bounds__(64) void splat_points_multi_kernel(const MultiParams mp)
+__global__ __launch_bounds__(kPointWaves * 64) void splat_points_multi_kernel(const MultiParams mp)
 {
     int s = 0;
     while (s + 1 < mp.n_scales && (long long)blockIdx.x >= mp.tile_begin[s + 1]) ++s;
-    small_body<CLEAR, SM, 2>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s]);
+    small_body<CLEAR, SM, 2, kPointWaves>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s]);
 }
 
 // bounding box (xmin, ymin, xmax, ymax) of every 64 consecutive points of points[b, :, :] (NaN points ignored; a group
@@ -1181,7 +1218,7 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
                            static_cast<float4*>(workspace));
     int nt = accv::tune_get("hm_nt", -1);
     if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;
-    const dim3 grid((unsigned)tiles), block(64);
+    const dim3 grid((unsigned)tiles), block(kPointWaves * 64);
     if (clear) {
         if (nt >= 2)
             hipLaunchKernelGGL((splat_points_multi_kernel<true, 4>), grid, block, 0, stream, mp);

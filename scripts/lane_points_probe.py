@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Where does splat_points_multi_kernel (the lane splat of BASELINE config 3) spend its time?  Calls the C-ABI entry point
+directly on pre-sampled lanes (group boxes given) and varies: no lanes at all (empty-tile floor), the number of lanes, the
+radius, the scales."""
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "accv-lab_amd")]
+
+import torch  # noqa: E402
+
+from accvlab import _amd_native as nat  # noqa: E402
+from accvlab.draw_heatmap import sample_lanes  # noqa: E402
+
+
+def gpu_us(fn, n=200):
+    for _ in range(30):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    lib = nat.lib()
+    B, SH, SW, L, P, Q = 32, 2160, 3840, 8, 24, 256
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.rand(B, L, 1, generator=g) * SW
+    t_ = torch.linspace(0, 1, P).view(1, 1, P)
+    xs = x0 + (torch.rand(B, L, 1, generator=g) - 0.5) * SW * 0.5 * t_ + 60 * torch.sin(6 * t_ + x0)
+    ys = SH * (1 - 0.9 * t_).expand(B, L, P)
+    lanes = torch.stack([xs, ys], -1).to(dev)
+    n = L * Q
+    ws_bytes = lib.accv_draw_points_workspace_bytes(B, n)
+    work = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    samples = sample_lanes(lanes, Q, group_boxes_ptr=work.data_ptr())
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(strides, counts, radius, clear=True):
+        maps = [torch.empty(B, int(SH / s), int(SW / s), device=dev) for s in strides]
+        k = len(maps)
+        ptrs = (ctypes.c_void_p * k)(*[m.data_ptr() for m in maps])
+        hs = (ctypes.c_int * k)(*[m.size(1) for m in maps])
+        ws_ = (ctypes.c_int * k)(*[m.size(2) for m in maps])
+        st = (ctypes.c_float * k)(*strides)
+        flags = (nat.HM_CLEAR if clear else 0) | nat.HM_GROUP_BOXES_GIVEN
+        fn = lambda: nat.check(lib.accv_draw_points_multiscale_f32(ptrs, hs, ws_, st, k, B, samples.data_ptr(), counts.data_ptr(),
+                                                                   n, radius, 6.0, 1.0, flags, work.data_ptr(), ws_bytes, stream), "points")
+        us = gpu_us(fn)
+        nbytes = sum(m.numel() * 4 for m in maps)
+        return {"us": round(us, 1), "GBps": round(nbytes / us / 1e3, 1), "kernel": nat.last_dispatch()}
+
+    full = torch.full((B,), n, dtype=torch.int32, device=dev)
+    none = torch.zeros(B, dtype=torch.int32, device=dev)
+    one = torch.full((B,), Q, dtype=torch.int32, device=dev)
+    for name, strides in (("all", (4.0, 8.0, 16.0)), ("s4", (4.0,)), ("s8", (8.0,)), ("s16", (16.0,))):
+        print(json.dumps({"scales": name, "no lanes (empty-tile floor)": run(strides, none, 2),
+                          "1 lane": run(strides, one, 2), "8 lanes r=2": run(strides, full, 2), "8 lanes r=0": run(strides, full, 0),
+                          "8 lanes r=2 in-place": run(strides, full, 2, clear=False)}))
+
+
+if __name__ == "__main__":
+    main()
