@@ -99,10 +99,11 @@ def config2(n=10_000):
     sync = torch.cuda.synchronize
     t_bg = _timeit(lambda: start_copy(tree, dev).get(), 10, 50, sync)
     t_in = _timeit(lambda: start_copy(tree, dev, use_background_thread=False).get(), 10, 50, sync)
-    t_naive = _timeit(lambda: [t.to(dev) for t in leaves], 2, 5, sync)
     small = wl.meta_tensor_tree(528, seed=0)
     t_bg_s = _timeit(lambda: start_copy(small, dev).get(), 20, 200, sync)
     t_in_s = _timeit(lambda: start_copy(small, dev, use_background_thread=False).get(), 20, 200, sync)
+    # last: 50 000 tiny device allocations leave the caching allocator in a state that slows whatever is timed next
+    t_naive = _timeit(lambda: [t.to(dev) for t in leaves], 2, 5, sync)
     _line(metric="multi_tensor_copier host->GPU copies of a 10k-leaf nested structure (copies/s)", value=1.0 / t_bg, unit="copies/s",
           steps=50, warmup=10, ms_per_step=t_bg * 1e3, dtype="u8",
           config={"workload": f"configs[2]: {len(leaves)} mixed fp32/int64 small CPU tensors ({nbytes} bytes) in a list of dicts of lists, "
