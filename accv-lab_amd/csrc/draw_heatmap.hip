@@ -630,13 +630,13 @@ __global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
 }
 
 // lane rasters of all scales in one launch: float sample points, two-level cull (SRC = 2), scale from the tile prefix
-constexpr int kPointWaves = 4;  // waves per tile of the lane raster
-template <bool CLEAR, int SM>
-__global__ __launch_bounds__(kPointWaves * 64) void splat_points_multi_kernel(const MultiParams mp)
+// NW = 4 when some scale is coarse enough for a tile to see many samples (decided on the host), else one wave per tile
+template <bool CLEAR, int SM, int NW>
+__global__ __launch_bounds__(NW * 64) void splat_points_multi_kernel(const MultiParams mp)
 {
     int s = 0;
     while (s + 1 < mp.n_scales && (long long)blockIdx.x >= mp.tile_begin[s + 1]) ++s;
-    small_body<CLEAR, SM, 2, kPointWaves>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s]);
+    small_body<CLEAR, SM, 2, NW>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s]);
 }
 
 // bounding box (xmin, ymin, xmax, ymax) of every 64 consecutive points of points[b, :, :] (NaN points ignored; a group
@@ -1218,18 +1218,32 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
                            static_cast<float4*>(workspace));
     int nt = accv::tune_get("hm_nt", -1);
     if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;
-    const dim3 grid((unsigned)tiles), block(kPointWaves * 64);
+    // a tile of a coarse scale is crossed by several lanes and has many sample groups to walk: share it among four waves
+    // when some scale averages >= 24 samples per tile (config 3: 7.5 / 30 / 113 at strides 4 / 8 / 16); fine scales alone
+    // keep one wave per tile (mostly empty tiles would only pay the barriers: 21.7 -> 23.8 us at stride 4)
+    bool heavy = false;
+    for (int i = 0; i < used; ++i)
+        heavy = heavy || (double)batch * num_points >= 24.0 * (double)mp.scale[i].n_tiles;
+    const dim3 grid((unsigned)tiles), block(heavy ? 256 : 64);
+#define ACCV_LAUNCH_POINTS(CL, SMV)                                                                       \
+    do {                                                                                                  \
+        if (heavy)                                                                                        \
+            hipLaunchKernelGGL((splat_points_multi_kernel<CL, SMV, 4>), grid, block, 0, stream, mp);      \
+        else                                                                                              \
+            hipLaunchKernelGGL((splat_points_multi_kernel<CL, SMV, 1>), grid, block, 0, stream, mp);      \
+    } while (0)
     if (clear) {
         if (nt >= 2)
-            hipLaunchKernelGGL((splat_points_multi_kernel<true, 4>), grid, block, 0, stream, mp);
+            ACCV_LAUNCH_POINTS(true, 4);
         else
-            hipLaunchKernelGGL((splat_points_multi_kernel<true, 0>), grid, block, 0, stream, mp);
+            ACCV_LAUNCH_POINTS(true, 0);
     } else {
         if (nt >= 2)
-            hipLaunchKernelGGL((splat_points_multi_kernel<false, 4>), grid, block, 0, stream, mp);
+            ACCV_LAUNCH_POINTS(false, 4);
         else
-            hipLaunchKernelGGL((splat_points_multi_kernel<false, 0>), grid, block, 0, stream, mp);
+            ACCV_LAUNCH_POINTS(false, 0);
     }
+#undef ACCV_LAUNCH_POINTS
     note_dispatch("splat_points_multi_kernel", 4, 8, clear, nt >= 2 ? 4 : 0, grid, block);
     return accv::check_launch("draw_heatmap multi-scale point splat kernel");
 }

@@ -176,3 +176,27 @@ def test_sampler_group_boxes_match_the_samples(q):
         else:
             want = torch.tensor([inf, inf, -inf, -inf])
         assert torch.equal(got[g], want), (g, got[g], want)
+
+
+def test_lane_splat_one_and_four_waves_per_tile_agree():
+    """splat_points_multi_kernel runs with one wave per tile when every scale is fine (few samples per tile) and with four
+    waves sharing a tile when some scale is coarse; both must equal the per-scale operator bit for bit"""
+    from accvlab import _amd_native as nat
+    from accvlab.draw_heatmap import draw_polylines_batched, draw_polylines_multiscale
+
+    dev = torch.device("cuda", 0)
+    pts, npts, nlanes = _lanes(4, 6, 14, 2048.0, 1024.0, seed=21, ragged=True)
+    pts_d, npts_d, nlanes_d = torch.from_numpy(pts).to(dev), torch.from_numpy(npts).to(dev), torch.from_numpy(nlanes).to(dev)
+    seen = set()
+    for strides in ((1.0,), (2.0, 4.0), (32.0,), (2.0, 64.0)):
+        for clear in (True, False):
+            shapes = [(4, int(1024 / s), int(2048 / s)) for s in strides]
+            base = [torch.rand(s_, generator=torch.Generator().manual_seed(7)).mul_(0.2).to(dev) for s_ in shapes]
+            fused = [b.clone() for b in base]
+            draw_polylines_multiscale(fused, pts_d, 128, 2, strides, 6.0, 0.8, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
+            seen.add("block(256)" in nat.last_dispatch())
+            for i, s in enumerate(strides):
+                ref = base[i].clone()
+                draw_polylines_batched(ref, pts_d, 128, 2, s, 6.0, 0.8, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
+                assert torch.equal(fused[i], ref), (strides, s, clear)
+    assert seen == {True, False}, "both launch shapes must have been exercised"
