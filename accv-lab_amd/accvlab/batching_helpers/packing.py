@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import batched_indexing_access_cuda as _ext
-from .ragged import RaggedBatch
+from .ragged import RaggedBatch, remember_host_sizes
 
 try:  # C++ per-sample loops (built by `make -C accv-lab_amd/csrc_host`); the python code below is the fallback
     from . import _bh_host as _bh
@@ -178,7 +178,8 @@ def _fast_pack(data_list, device):
         small = _bh.pack_cpu(data_list, True, _DIRECT_PADDED_BYTES)
         if small is None:
             return None
-        return small[0].to(target, non_blocking=True), small[1].to(target, non_blocking=True)
+        return small[0].to(target, non_blocking=True), \
+            remember_host_sizes(small[1].to(target, non_blocking=True), small[1].tolist())
     if first.device.type != "cuda" or (target is not None and target != first.device):
         return None
     got = _bh.cat_leaves(data_list, True)         # GPU samples: trim/check loop + cat in C++, then the pack kernel
@@ -188,7 +189,7 @@ def _fast_pack(data_list, device):
     if flat.numel() == 0 or width == 0:
         return None
     meta_dev = meta.to(flat.device, non_blocking=True)
-    return _ext.pack_rows(flat, meta_dev[0], meta_dev[1], width), meta_dev[1]
+    return _ext.pack_rows(flat, meta_dev[0], meta_dev[1], width), remember_host_sizes(meta_dev[1], sizes_cpu.tolist())
 
 
 def combine_data(data_list: Sequence[Union[Sequence, torch.Tensor]], other_with_same_sample_sizes: RaggedBatch = None,
@@ -226,7 +227,7 @@ def combine_data(data_list: Sequence[Union[Sequence, torch.Tensor]], other_with_
         lens = [_valid_len(t) for t in leaves]
         padded, sizes_cpu = _build_padded(leaves, lens, width, proto, device)
         if share is None:
-            return RaggedBatch(padded, sample_sizes=sizes_cpu.to(device))
+            return RaggedBatch(padded, sample_sizes=remember_host_sizes(sizes_cpu.to(device), lens))
         assert len(leaves) == share.sample_sizes.shape[0], "Number of samples does not match `other_with_same_sample_sizes`"
         assert (len(leaves), width) == tuple(share.mask.shape), \
             "Needed mask dimension does not match `other_with_same_sample_sizes`"
@@ -249,6 +250,7 @@ def combine_data(data_list: Sequence[Union[Sequence, torch.Tensor]], other_with_
     padded, sizes_cpu = _build_padded(leaves, lens, width, proto, device)
     padded = padded.reshape(*batch_shape, *padded.shape[1:])
     if share is None:
-        return RaggedBatch(padded, sample_sizes=sizes_cpu.reshape(batch_shape).to(device), non_uniform_dim=nb)
+        return RaggedBatch(padded, sample_sizes=remember_host_sizes(sizes_cpu.reshape(batch_shape).to(device), lens),
+                           non_uniform_dim=nb)
     assert tuple(share.sample_sizes.shape) == tuple(batch_shape), "Sample sizes shape does not match required batch shape"
     return share.create_with_sample_sizes_like_self(padded, non_uniform_dim=nb, device=device)

@@ -32,6 +32,28 @@ except ImportError:  # pragma: no cover
     _bh = None
 
 
+def remember_host_sizes(sizes: torch.Tensor, values) -> torch.Tensor:
+    """Attach the host copy of a DEVICE sample-size tensor to it (row-major python ints) so that consumers which need the
+    sizes on the host (``split``) do not have to read them back — a device synchronisation.  The copy is trusted only while
+    the tensor's version counter is unchanged, so any in-place edit of the tensor invalidates it."""
+    try:
+        sizes._accv_host_sizes = (list(values), sizes._version)
+    except Exception:  # pragma: no cover - tensor subclasses without a __dict__
+        pass
+    return sizes
+
+
+def host_sizes(sizes: torch.Tensor) -> list:
+    """Row-major python ints of ``sizes``; from the attached host copy when it is still valid, else one read-back."""
+    hit = getattr(sizes, "_accv_host_sizes", None)
+    if hit is not None and hit[1] == sizes._version and len(hit[0]) == sizes.numel():
+        return hit[0]
+    values = sizes.reshape(-1).tolist()
+    if sizes.is_cuda:
+        remember_host_sizes(sizes, values)
+    return values
+
+
 class RaggedBatch:
     """Batch whose samples differ in size along one ("non-uniform") dimension.
 
@@ -407,7 +429,7 @@ class RaggedBatch:
         nb = self._num_batch_dims
         src = self if self._non_uniform_dim == nb else self.get_non_uniform_dimension_transposed_to(nb)
         data = src.tensor
-        sizes = src.sample_sizes.reshape(-1).tolist()
+        sizes = host_sizes(src.sample_sizes)     # no device read-back when the sizes came from the host (combine_data)
         back = self._non_uniform_dim - nb
         flat = data.reshape(-1, *data.shape[nb:]) if nb > 1 else data
         width = flat.shape[1] if flat.dim() > 1 else 0

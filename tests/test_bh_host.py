@@ -166,3 +166,37 @@ def test_split_views_share_the_version_counter_of_the_batch():
     rb2.split()[0].zero_()
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         y.backward()
+
+
+@pytest.mark.gpu
+def test_split_uses_the_host_copy_of_the_sizes_and_detects_edits():
+    """combine_data knows the sample sizes on the host; split() of the result (and of batches sharing its size tensor) must
+    not read them back from the device — and must, as soon as the size tensor was edited in place"""
+    from accvlab.batching_helpers import ragged
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    samples = [torch.rand(int(torch.randint(0, 9, (1,), generator=g)), 3, generator=g) for _ in range(12)]
+    for src in (samples, [t.to(dev) for t in samples]):          # CPU samples -> GPU, and GPU samples
+        rb = combine_data(src, device=dev)
+        hit = getattr(rb.sample_sizes, "_accv_host_sizes", None)
+        assert hit is not None and hit[0] == [t.shape[0] for t in samples]
+        calls = []
+        real = torch.Tensor.tolist
+        torch.Tensor.tolist = lambda self: (calls.append(1), real(self))[1]
+        try:
+            parts = rb.split()
+            other = rb.create_with_sample_sizes_like_self(rb.tensor * 2)      # shares the size tensor
+            parts2 = other.split()
+            tr = rb.get_non_uniform_dimension_transposed_to(2).split()
+        finally:
+            torch.Tensor.tolist = real
+        assert calls == [], "split() read the sizes back although their host copy was valid"
+        assert all(torch.equal(a.cpu(), b) for a, b in zip(parts, samples))
+        assert all(torch.equal(a.cpu(), b * 2) for a, b in zip(parts2, samples))
+        assert all(torch.equal(a.cpu(), b.t()) for a, b in zip(tr, samples))
+        # an in-place edit of the sizes bumps their version: the host copy is dropped and the new sizes are used
+        rb.sample_sizes.clamp_(max=1)
+        edited = rb.split()
+        assert [p.shape[0] for p in edited] == [min(1, t.shape[0]) for t in samples]
+    assert ragged.host_sizes(torch.tensor([3, 1, 2])) == [3, 1, 2]
