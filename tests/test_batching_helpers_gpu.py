@@ -332,3 +332,55 @@ def test_error_behaviour_matches_reference():
     # empty index tensor => early return with the filler (reference cu:253-255)
     out = ext.forward(d, torch.zeros(2, 0, dtype=torch.int64, device=DEV), n, 5.0)
     assert out.shape == (2, 0, 3)
+
+
+@pytest.mark.parametrize("batch,width,k,inner,dtype", [
+    (70_000, 3, 2, (1,), torch.float32),        # more samples than the grid's y extent: the sample loop of the row kernels
+    (2, 5, 4, (4100,), torch.float32),          # 16 KB rows: more vectors per row than lanes per row (vector loop)
+    (3, 7, 5, (3,), torch.float16),             # 6-byte rows: 2-byte vectors
+    (3, 7, 5, (5,), torch.bool),                # 5-byte rows: byte vectors
+    (1, 300, 300, (), torch.float64),           # scalar rows, one sample: 256 slots per workgroup
+])
+def test_row_kernels_launch_geometry_extremes(batch, width, k, inner, dtype):
+    """the division-free 2-D launch geometry of the ragged byte movers (slot group x sample, 2^k lanes per row) at its
+    corners, for gather (+fill), scatter, pair mapping, pad fill and pack, bit-exact against the oracle"""
+    from accvlab.batching_helpers import batched_indexing_access_cuda as ext
+
+    g = np.random.RandomState(batch % 1000 + width)
+    shape = (batch, width) + inner
+    if dtype.is_floating_point:
+        data = torch.from_numpy(g.randn(*shape)).to(dtype)
+    elif dtype == torch.bool:
+        data = torch.from_numpy(g.randint(0, 2, shape)).to(dtype)
+    else:
+        data = torch.from_numpy(g.randint(0, 100, shape)).to(dtype)
+    idx = np.stack([g.permutation(width)[:k] for _ in range(min(batch, 64))]).astype(np.int64)
+    idx = np.tile(idx, (-(-batch // idx.shape[0]), 1))[:batch]
+    counts = g.randint(0, k + 1, batch).astype(np.int64)
+    d_dev, i_dev, c_dev = data.to(DEV), torch.from_numpy(idx).to(DEV), torch.from_numpy(counts).to(DEV)
+    dn = data.numpy() if dtype != torch.bfloat16 else None
+    # gather + fill through the public op's extension entry (float dtypes only there) or gather_rows
+    out = torch.zeros((batch, k) + inner, dtype=dtype, device=DEV)
+    ext.gather_rows(d_dev, i_dev, c_dev, k, out)
+    want = oracle.gather(dn, idx, counts, 0)
+    assert np.array_equal(out.cpu().numpy(), want)
+    # scatter the gathered rows back into a marked copy
+    into = torch.full(shape, 1 if dtype == torch.bool else 7, dtype=dtype)
+    dst = into.to(DEV)
+    ext.scatter_rows(out, i_dev, c_dev, k, dst)
+    assert np.array_equal(dst.cpu().numpy(), oracle.scatter_insert(want, idx, counts, into.numpy()))
+    # pad fill (SetPaddedTo) on a ragged view of the same data
+    rb_counts = torch.from_numpy(g.randint(0, width + 1, batch).astype(np.int64))
+    filled = d_dev.clone()
+    ext.set_ragged_batch_padded_to_filler_value_in_place(filled, rb_counts.to(DEV), 3)
+    assert np.array_equal(filled.cpu().numpy(), oracle.pad_fill(dn, rb_counts.numpy(), 3))
+    # pack: flat rows -> padded
+    if batch <= 1000:
+        sizes = rb_counts
+        flat = torch.cat([data[i, : int(sizes[i])] for i in range(batch)]) if int(sizes.sum()) else data[:0, 0]
+        offs = torch.cumsum(sizes, 0) - sizes
+        packed = ext.pack_rows(flat.to(DEV).contiguous(), offs.to(DEV), sizes.to(DEV), width)
+        wantp = torch.zeros(shape, dtype=dtype)
+        for i in range(batch):
+            wantp[i, : int(sizes[i])] = data[i, : int(sizes[i])]
+        assert torch.equal(packed.cpu(), wantp)
