@@ -114,10 +114,18 @@ def _data_dtype(t, name, allow_bool=False) -> None:
 
 
 @functools.lru_cache(maxsize=256)
-@functools.lru_cache(maxsize=256)
 def element_bits(value, dtype: torch.dtype) -> int:
     """Byte pattern (as an unsigned integer, little endian) of ``value`` converted to ``dtype`` with the
     conversion rules of ``static_cast<scalar_t>(double)`` used by the reference."""
+    # normalise to a plain python number first: the cache below must never key on a mutable object (0-dim tensors, numpy
+    # scalars) whose value can change under the same identity
+    if not isinstance(value, (bool, int, float)):
+        value = float(value)
+    return _element_bits(value, dtype)
+
+
+@functools.lru_cache(maxsize=256)
+def _element_bits(value, dtype: torch.dtype) -> int:
     if dtype == torch.float32:
         return struct.unpack("<I", struct.pack("<f", float(value)))[0]
     if dtype == torch.float64:
