@@ -172,22 +172,23 @@ __global__ __launch_bounds__(256) void insert_const_kernel(const RaggedDesc d, c
     }
 }
 
-// data[i, j, :] = pattern for j >= counts[i]
+// data[i, j, :] = pattern for j >= counts[i].  The padding of a sample is ONE contiguous span of vectors
+// [(i*width + count) * row_vecs, (i+1)*width * row_vecs): blockIdx.x strides over that span from its START, so no
+// workgroup is launched only to find its slots filled (the per-slot grid spent most of its time on those: 3.7 TB/s of
+// the padded bytes at 1 GB), and the host caps the workgroups per sample so that a large fill loops instead.
 template <int VB>
 __global__ __launch_bounds__(256) void pad_fill_kernel(void* __restrict__ data_, const void* __restrict__ counts,
                                                        int counts_i64, long long batch, long long width,
-                                                       long long row_vecs, const RowGeom g,
-                                                       typename VecOf<VB>::type pattern)
+                                                       long long row_vecs, typename VecOf<VB>::type pattern)
 {
     using V = typename VecOf<VB>::type;
     V* data = static_cast<V*>(data_);
-    long long j;
-    int v0, lanes;
-    if (!row_of_thread(g, width, j, v0, lanes)) return;
+    const long long step = (long long)gridDim.x * 256;
     for (long long i = blockIdx.y; i < batch; i += gridDim.y) {
-        if (j < load_int(counts, i, counts_i64)) continue;
-        const long long to = (i * width + j) * row_vecs;
-        for (long long v = v0; v < row_vecs; v += lanes) data[to + v] = pattern;
+        const long long c = min(max(load_int(counts, i, counts_i64), 0ll), width);
+        const long long end = (i + 1) * width * row_vecs;
+        for (long long v = (i * width + c) * row_vecs + (long long)blockIdx.x * 256 + threadIdx.x; v < end; v += step)
+            data[v] = pattern;
     }
 }
 
@@ -621,10 +622,14 @@ int accv_ragged_pad_fill(void* data, const void* counts, long long batch, long l
     int vb = pick_vec(row_bytes, {data});
     if (vb < elem_size) return accv::fail(ACCV_EINVAL, "ragged_pad_fill: data not aligned to its element size");
     const long long row_vecs = row_bytes / vb;
-    const RowLaunch rl = row_launch(batch, width, row_vecs);
-    if (!rl.ok) return accv::fail(ACCV_EINVAL, "ragged_pad_fill: width %lld exceeds the grid limit", width);
-    DISPATCH_VB(vb, hipLaunchKernelGGL((pad_fill_kernel<VB>), rl.grid, dim3(256), 0, stream, data, counts, counts_i64,
-                                       batch, width, row_vecs, rl.geom, make_pattern<VB>(elem_bits, elem_size)));
+    // one store per wave while that fills the chip; beyond ~16k workgroups each one strides over its sample's span
+    const long long gy = batch < 65535 ? batch : 65535;
+    const long long span_blocks = (width * row_vecs + 255) / 256;
+    long long gx = 16384 / gy;
+    gx = gx < 1 ? 1 : gx;
+    gx = span_blocks < gx ? span_blocks : gx;
+    DISPATCH_VB(vb, hipLaunchKernelGGL((pad_fill_kernel<VB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, data,
+                                       counts, counts_i64, batch, width, row_vecs, make_pattern<VB>(elem_bits, elem_size)));
     return accv::check_launch("ragged_pad_fill");
 }
 

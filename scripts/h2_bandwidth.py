@@ -88,6 +88,15 @@ def main():
         t2 = timeit(lambda: ext.mask_to_indices(mask2))
         print(json.dumps({"mask_to_indices": {"batch": b2, "width": w2}, "us": t2 * 1e6,
                           "GBps_of_mask_plus_index_bytes": (mask2.numel() * 9) / t2 / 1e9}))
+    # pad fill at a size where the launch ramp no longer matters (the 64 x 8192 case above writes only ~50 MB)
+    b3, n3 = 512, 8192
+    data3 = torch.randn(b3, n3, d, device=dev)
+    counts3 = torch.randint(n3 // 4, n3 + 1, (b3,), generator=g).to(dev)
+    rb3 = RaggedBatch(data3, sample_sizes=counts3)
+    t3 = timeit(lambda: rb3.set_padded_to(0.0))
+    pad3 = int((n3 - counts3).sum()) * row
+    print(json.dumps({"pad_fill_large": {"batch": b3, "rows": n3, "row_bytes": row, "padded_bytes": pad3}, "us": t3 * 1e6,
+                      "GBps_of_padded_bytes": pad3 / t3 / 1e9}))
     for line in out_lines:
         print(json.dumps(line))
 
