@@ -22,6 +22,7 @@ HM_WRITE_THROUGH = 8
 HM_GROUP_BOXES_GIVEN = 16
 HM_TILE_ROWS_16 = 32
 HM_TILE_ROWS_8 = 64
+HM_CALLER_SCALE_ORDER = 256
 HM_PLAIN_STORES = 128
 
 _vp = ctypes.c_void_p

@@ -18,6 +18,7 @@ import torch
 
 from .. import _amd_native as _nat
 from ..lane_helpers.polyline import ops as _poly
+from . import ops as _ops
 from .ops import draw_heatmap_batched
 
 _cache: dict = {}
@@ -184,7 +185,7 @@ def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: in
     ws_ = (ctypes.c_int * k)(*[hm.size(2) for hm in heatmaps])
     st = (ctypes.c_float * k)(*strides)
     flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if sizes.dtype == torch.int64 else 0) | \
-        (_nat.HM_GROUP_BOXES_GIVEN if boxes_by_sampler else 0)
+        (_nat.HM_GROUP_BOXES_GIVEN if boxes_by_sampler else 0) | _ops._FORCED_FLAGS
     with _nat.device_guard(dev):
         status = lib.accv_draw_points_multiscale_f32(
             ptrs, hs, ws_, st, k, b, samples.data_ptr(), sizes.data_ptr(), n, int(radius),

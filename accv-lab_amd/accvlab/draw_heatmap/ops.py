@@ -313,7 +313,7 @@ def draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diamete
     hs = (ctypes.c_int * n)(*[hm.size(1) for hm in heatmaps])
     ws = (ctypes.c_int * n)(*[hm.size(2) for hm in heatmaps])
     st = (ctypes.c_float * n)(*strides)
-    flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0)
+    flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0) | _FORCED_FLAGS
     dev = heatmaps[0].device
     with _nat.device_guard(dev):
         status = _nat.lib().accv_draw_heatmap_multiscale_f32(

@@ -960,6 +960,22 @@ int check_common(const void* hm, int h, int w, float factor, const char* who)
     return ACCV_OK;
 }
 
+// Workgroups are dispatched in linear order: put the COARSE scales first.  Their tiles see the same objects / lane samples on
+// fewer pixels, i.e. the longest per-tile chains, and started last they are the tail of the launch; the many short tiles of
+// the fine scales fill in behind them (config 3: box maps 19.4 -> 17.4 us, in-place 24.9 -> 22.0, lane raster 40.8 -> 38.7;
+// profiles/r02_scale_order_ab.log).
+inline void coarse_scales_first(MultiParams& mp)
+{
+    std::stable_sort(mp.scale, mp.scale + mp.n_scales,
+                     [](const SplatParams& a, const SplatParams& b) { return a.n_tiles < b.n_tiles; });
+    long long tiles = 0;
+    for (int i = 0; i < mp.n_scales; ++i) {
+        mp.tile_begin[i] = tiles;
+        tiles += mp.scale[i].n_tiles;
+    }
+    mp.tile_begin[mp.n_scales] = tiles;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1123,6 +1139,7 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
     mp.tile_begin[used] = tiles;
     if (used == 0 || tiles == 0) return ACCV_OK;
     if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: %lld tiles exceed the grid limit", tiles);
+    if (!(flags & ACCV_HM_CALLER_SCALE_ORDER)) coarse_scales_first(mp);
     int nt = accv::tune_get("hm_nt", -1);
     if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;   // same store policy as the single-scale path
     const dim3 grid((unsigned)tiles), block(64);
@@ -1210,6 +1227,7 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
     mp.tile_begin[used] = tiles;
     if (used == 0 || tiles == 0) return ACCV_OK;
     if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: %lld tiles exceed the grid limit", tiles);
+    if (!(flags & ACCV_HM_CALLER_SCALE_ORDER)) coarse_scales_first(mp);
     const long long total_groups = (long long)batch * n_groups;
     if (total_groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: too many point groups");
     if (total_groups > 0 && !(flags & ACCV_HM_GROUP_BOXES_GIVEN))

@@ -46,6 +46,9 @@ extern "C" {
                                     cover >= 3/4 of its area (sum of (2r+1)^2), plain elsewhere.  Same results. */
 #define ACCV_HM_TILE_ROWS_16 32u /* hint: 128 x 32 pixel wave tiles (half the waves, twice the registers per wave) */
 #define ACCV_HM_TILE_ROWS_8 64u  /* hint: 128 x 16 pixel wave tiles (the default).  Same results either way. */
+#define ACCV_HM_CALLER_SCALE_ORDER 256u /* multi-scale calls only: keep the caller's order of scales in the launch.  Default:
+                                         * coarse scales (fewest tiles, longest per-tile work) are dispatched first.  Same
+                                         * results either way. */
 
 const char* accv_last_error(void);
 int accv_version(void);

@@ -190,3 +190,33 @@ def test_density_adaptive_store_policy_is_value_neutral():
         draw_heatmap_batched(hm, rb(centers), rb(radii), 6.0, 0.9, rb(labels), write_through=wt)
         outs.append(hm)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("clear", [True, False])
+def test_scale_order_inside_the_launch_does_not_change_results(clear):
+    """Default: coarse scales are dispatched first; ACCV_HM_CALLER_SCALE_ORDER keeps the caller's order.  Same maps."""
+    from accvlab import _amd_native as nat
+    from accvlab.draw_heatmap import draw_heatmap_multiscale, draw_polylines_multiscale, ops
+
+    b, sw, sh = 4, 960, 544
+    strides = (4.0, 16.0, 8.0)     # deliberately unsorted
+    crb, brb = _objects(b, 24, sw, sh, seed=21)
+    base = [torch.rand(b, int(sh / s), int(sw / s), generator=torch.Generator().manual_seed(i)).mul_(0.2).to(DEV)
+            for i, s in enumerate(strides)]
+    g = torch.Generator().manual_seed(5)
+    lanes = (torch.rand(b, 3, 9, 2, generator=g) * torch.tensor([sw, sh])).to(DEV)
+    results = {}
+    for label, flag in (("coarse first", 0), ("caller order", nat.HM_CALLER_SCALE_ORDER)):
+        ops._FORCED_FLAGS = flag
+        try:
+            boxes = [t.clone() for t in base]
+            draw_heatmap_multiscale(boxes, crb, brb, strides, 6.0, 0.8, clear=clear)
+            assert "splat_multi_kernel" in nat.last_dispatch()
+            lane_maps = [t.clone() for t in base]
+            draw_polylines_multiscale(lane_maps, lanes, 64, 2, strides, clear=clear)
+            assert "splat_points_multi_kernel" in nat.last_dispatch()
+        finally:
+            ops._FORCED_FLAGS = 0
+        results[label] = boxes + lane_maps
+    for a, c in zip(results["coarse first"], results["caller order"]):
+        assert torch.equal(a, c)
