@@ -39,6 +39,7 @@ SIGNATURES = {
     "accv_last_error": (ctypes.c_char_p, []),
     "accv_version": (_i, []),
     "accv_draw_heatmap_last_dispatch": (ctypes.c_char_p, []),
+    "accv_draw_heatmap_time_next_launch": (_i, [_vp, _vp]),
     "accv_draw_heatmap_flat_workspace_bytes": (_sz, [_i, _i]),
     "accv_draw_heatmap_flat_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _u, _vp, _sz, _vp]),
     "accv_draw_heatmap_batched_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _u, _vp]),

@@ -24,6 +24,7 @@
 // csrc/draw_heatmap_cuda.cu:29-165 of the reference (one thread per object, serial atomicMax splat).
 // Plane offsets are 64-bit (the reference's are int and overflow for class-wise full-HD batches).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <climits>
@@ -674,7 +675,33 @@ void note_dispatch(const char* kernel, int px, int r, bool clear, int sm, const 
              sm, grid.x, grid.y, grid.z, block.x);
 }
 
-int launch_splat_small(SplatParams p, long long planes, bool clear, int sm, hipStream_t stream)
+// one-shot, per thread: events for the splat launch of the next flat / batched call (accv_draw_heatmap_time_next_launch)
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+LaunchEvents& launch_events()
+{
+    static thread_local LaunchEvents ev;
+    return ev;
+}
+LaunchEvents take_launch_events()
+{
+    const LaunchEvents ev = launch_events();
+    launch_events() = LaunchEvents{};
+    return ev;
+}
+// same kernel, same launch parameters; with events the kernel's own start / stop time stamps are recorded (hip_ext.h)
+template <class K>
+inline void launch_maybe_timed(K kernel, const dim3& grid, const dim3& block, hipStream_t stream, const LaunchEvents& ev,
+                               const SplatParams& p)
+{
+    if (ev.start || ev.stop)
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev.start, ev.stop, 0, p);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, p);
+}
+
+int launch_splat_small(SplatParams p, long long planes, bool clear, int sm, hipStream_t stream, const LaunchEvents& ev)
 {
     p.tiles_x = (p.W + 127) / 128;
     p.tiles_y = (p.H + 15) / 16;
@@ -690,14 +717,14 @@ int launch_splat_small(SplatParams p, long long planes, bool clear, int sm, hipS
     }
     if (clear) {
         if (sm >= 2)
-            hipLaunchKernelGGL((splat_small_kernel<true, 4>), grid, dim3(64), 0, stream, p);
+            launch_maybe_timed(splat_small_kernel<true, 4>, grid, dim3(64), stream, ev, p);
         else
-            hipLaunchKernelGGL((splat_small_kernel<true, 0>), grid, dim3(64), 0, stream, p);
+            launch_maybe_timed(splat_small_kernel<true, 0>, grid, dim3(64), stream, ev, p);
     } else {
         if (sm >= 2)
-            hipLaunchKernelGGL((splat_small_kernel<false, 4>), grid, dim3(64), 0, stream, p);
+            launch_maybe_timed(splat_small_kernel<false, 4>, grid, dim3(64), stream, ev, p);
         else
-            hipLaunchKernelGGL((splat_small_kernel<false, 0>), grid, dim3(64), 0, stream, p);
+            launch_maybe_timed(splat_small_kernel<false, 0>, grid, dim3(64), stream, ev, p);
     }
     note_dispatch("splat_small_kernel", 4, 8, clear, sm >= 2 ? 4 : 0, grid, dim3(64));
     return accv::check_launch("draw_heatmap small-splat kernel");
@@ -858,7 +885,7 @@ __global__ void fill_tail_kernel(float* __restrict__ dst, size_t n, float value)
 // store mode SM: 0 plain, 4 write-through non-temporal (sc1 nt).  (The A/B build also instantiates 1 = non-temporal and
 // 2 = write-through, and 4-wave workgroups: -DACCV_TUNE_BUILD.)
 template <int PX, int R, int WPG = kWavesPerGroup>
-int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_t stream)
+int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_t stream, const LaunchEvents& ev)
 {
     p.tiles_x = (p.W + 32 * PX - 1) / (32 * PX);
     p.tiles_y = (p.H + 2 * R - 1) / (2 * R);
@@ -874,12 +901,13 @@ int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_
         if (groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap: %lld tiles exceed the grid limit", p.n_tiles);
         grid = dim3((unsigned)groups);
     }
+#define ACCV_LAUNCH_ONE(KERNEL) launch_maybe_timed(KERNEL, grid, block, stream, ev, p)
 #define ACCV_LAUNCH_SM(SMV)                                                                              \
     do {                                                                                                 \
         if (clear)                                                                                       \
-            hipLaunchKernelGGL((splat_kernel<PX, R, true, SMV, WPG>), grid, block, 0, stream, p);    \
+            ACCV_LAUNCH_ONE((splat_kernel<PX, R, true, SMV, WPG>));                                      \
         else                                                                                             \
-            hipLaunchKernelGGL((splat_kernel<PX, R, false, SMV, WPG>), grid, block, 0, stream, p);   \
+            ACCV_LAUNCH_ONE((splat_kernel<PX, R, false, SMV, WPG>));                                     \
     } while (0)
     if constexpr (PX == 4) {
         switch (sm) {
@@ -893,7 +921,7 @@ int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_
                     sm = 0;
                     ACCV_LAUNCH_SM(0);
                 } else {
-                    hipLaunchKernelGGL((splat_kernel<PX, R, false, 5, WPG>), grid, block, 0, stream, p);
+                    ACCV_LAUNCH_ONE((splat_kernel<PX, R, false, 5, WPG>));
                 }
                 break;
             default: sm = 0; ACCV_LAUNCH_SM(0); break;
@@ -903,11 +931,12 @@ int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_
         ACCV_LAUNCH_SM(0);
     }
 #undef ACCV_LAUNCH_SM
+#undef ACCV_LAUNCH_ONE
     note_dispatch("splat_kernel", PX, R, clear, sm, grid, block);
     return accv::check_launch("draw_heatmap splat kernel");
 }
 
-int dispatch_splat(SplatParams p, long long planes, bool clear, unsigned flags, hipStream_t stream)
+int dispatch_splat(SplatParams p, long long planes, bool clear, unsigned flags, hipStream_t stream, const LaunchEvents& ev)
 {
     const bool small_hint = (flags & ACCV_HM_SMALL_RADII) != 0;
     const bool vec4 = (p.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.hm) & 15u) == 0);
@@ -940,14 +969,14 @@ int dispatch_splat(SplatParams p, long long planes, bool clear, unsigned flags, 
             rows = 8;
     }
     if (!p.labels) p.labels = p.radii;  // branch-free candidate loads: always a readable array (ignored when cls < 0)
-    if (!vec4) return launch_splat<1, 8>(p, planes, clear, 0, stream);
+    if (!vec4) return launch_splat<1, 8>(p, planes, clear, 0, stream, ev);
     const int small = accv::tune_get("hm_small", -1);   // point-like objects: the caller's ACCV_HM_SMALL_RADII hint
-    if (small > 0 || (small < 0 && small_hint)) return launch_splat_small(p, planes, clear, nt, stream);
-    if (rows == 16) return launch_splat<4, 16>(p, planes, clear, nt, stream);
+    if (small > 0 || (small < 0 && small_hint)) return launch_splat_small(p, planes, clear, nt, stream, ev);
+    if (rows == 16) return launch_splat<4, 16>(p, planes, clear, nt, stream, ev);
 #ifdef ACCV_TUNE_BUILD
-    if (accv::tune_get("hm_wpg", kWavesPerGroup) == 4) return launch_splat<4, 8, 4>(p, planes, clear, nt, stream);
+    if (accv::tune_get("hm_wpg", kWavesPerGroup) == 4) return launch_splat<4, 8, 4>(p, planes, clear, nt, stream, ev);
 #endif
-    return launch_splat<4, 8>(p, planes, clear, nt, stream);
+    return launch_splat<4, 8>(p, planes, clear, nt, stream, ev);
 }
 
 int check_common(const void* hm, int h, int w, float factor, const char* who)
@@ -980,6 +1009,12 @@ inline void coarse_scales_first(MultiParams& mp)
 
 extern "C" {
 
+int accv_draw_heatmap_time_next_launch(void* start_event, void* stop_event)
+{
+    launch_events() = LaunchEvents{static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event)};
+    return ACCV_OK;
+}
+
 size_t accv_draw_heatmap_flat_workspace_bytes(int num_planes, int num_objects)
 {
     if (num_planes < 0 || num_objects < 0) return 0;
@@ -994,6 +1029,7 @@ int accv_draw_heatmap_flat_f32(float* heatmaps, int num_planes, int height, int 
                                size_t workspace_bytes, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const LaunchEvents ev = take_launch_events();   // consumed by this call whether or not it launches
     if (int rc = check_common(heatmaps, height, width, diameter_to_sigma_factor, "draw_heatmap")) return rc;
     if (num_planes < 0 || num_objects < 0) return accv::fail(ACCV_EINVAL, "draw_heatmap: negative count");
     if (num_objects > (1 << 30)) return accv::fail(ACCV_EINVAL, "draw_heatmap: more than 2^30 objects");
@@ -1040,7 +1076,7 @@ int accv_draw_heatmap_flat_f32(float* heatmaps, int num_planes, int height, int 
     p.W = width;
     p.factor = diameter_to_sigma_factor;
     p.k = k_scale;
-    return dispatch_splat(p, num_planes, clear, flags, stream);
+    return dispatch_splat(p, num_planes, clear, flags, stream, ev);
 }
 
 int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, int height, int width,
@@ -1049,6 +1085,7 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
                                   float k_scale, unsigned flags, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const LaunchEvents ev = take_launch_events();   // consumed by this call whether or not it launches
     if (int rc = check_common(heatmap, height, width, diameter_to_sigma_factor, "draw_heatmap_batched")) return rc;
     if (batch < 0 || max_num_targets < 0 || num_classes < 0)
         return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: negative count");
@@ -1078,7 +1115,7 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
     p.k = k_scale;
     p.counts_i64 = (flags & ACCV_HM_COUNTS_I64) ? 1 : 0;
     const long long planes = (long long)batch * (num_classes > 0 ? num_classes : 1);
-    return dispatch_splat(p, planes, clear, flags, stream);
+    return dispatch_splat(p, planes, clear, flags, stream, ev);
 }
 
 int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights, const int* widths, const float* strides,

@@ -61,6 +61,14 @@ const char* accv_draw_heatmap_last_dispatch(void);
  * Gaussian heat-map rasteriser.
  */
 
+/* Profiling aid (no reference counterpart): the splat kernel of the NEXT accv_draw_heatmap_flat_f32 /
+ * accv_draw_heatmap_batched_f32 call made by the calling thread records `start_event` when it begins to execute and
+ * `stop_event` when it has finished (hipExtLaunchKernel), i.e. the kernel's own duration, without the dispatch gap that
+ * separates back-to-back launches on a stream.  Both are hipEvent_t with timing enabled (either may be NULL).  One-shot:
+ * that call consumes the pair whether or not it launches (a call that returns early leaves the events unrecorded);
+ * (NULL, NULL) cancels.  bench.py derives roofline.kernel_ms from it; kernel and launch parameters are unchanged. */
+int accv_draw_heatmap_time_next_launch(void* start_event, void* stop_event);
+
 /* Replaces draw_heatmap_launcher / draw_heatmap_cuda  (packages/draw_heatmap/accvlab/draw_heatmap/csrc/
  * draw_heatmap_cuda.cu:29-41,62-89; kernel include/draw_heatmap_cuda_kernel.cuh:51-74).
  * heatmaps f32[P,H,W] (in/out), centers i32[N,2] (x,y), radii i32[N], heatmap_idxes i32[N].

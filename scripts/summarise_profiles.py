@@ -24,8 +24,18 @@ def main(out):
            if "splat_kernel<" in r["Kernel_Name"] and "true" in r["Kernel_Name"].split("splat_kernel")[1][:20]]
     if dur:
         res["clear_kernel"] = {"name": next(r["Kernel_Name"] for r in trace if "splat_kernel" in r["Kernel_Name"]),
-                               "launches": len(dur), "avg_us_all": sum(dur) / len(dur) / 1e3,
-                               "avg_us_last500": sum(dur[-500:]) / len(dur[-500:]) / 1e3}
+                               "launches": len(dur), "avg_us_all": sum(dur) / len(dur) / 1e3}
+        # bench.py says which of its fused clear+draw launches were the timed region (back to back) and which were the
+        # launches timed one by one (spaced by their events): roofline.trace_index of the line it printed under the profiler
+        try:
+            with open(os.path.join(out, "bench_under_rocprof.json")) as fh:
+                idx = json.loads([l for l in fh.read().splitlines() if l.startswith("{")][-1])["roofline"]["trace_index"]
+            a, n = idx["timed_region_first_launch"], idx["timed_region_launches"]
+            res["clear_kernel"]["avg_us_timed_region_back_to_back"] = sum(dur[a:a + n]) / n / 1e3
+            b, m = idx["spaced_first_launch"], idx["spaced_launches"]
+            res["clear_kernel"]["avg_us_spaced_launches"] = sum(dur[b:b + m]) / m / 1e3
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            res["clear_kernel"]["avg_us_last500"] = sum(dur[-500:]) / len(dur[-500:]) / 1e3
     stats = rows(os.path.join(out, "trace", "**", "*kernel_stats.csv"))
     res["kernel_stats_top"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage")}
                                for r in stats[:6]]
@@ -64,6 +74,7 @@ def main(out):
             line = [l for l in fh.read().splitlines() if l.startswith("{")][-1]
         b = json.loads(line)
         res["bench_under_rocprof"] = {"ms_per_step": b["ms_per_step"], "kernel_ms": b["roofline"].get("kernel_ms"),
+                                      "kernel_ms_spaced_launches": b["roofline"].get("kernel_ms_spaced_launches"),
                                       "frac": b["roofline"]["frac"], "value": b["value"]}
     except Exception as e:  # noqa: BLE001
         res["bench_under_rocprof"] = f"unreadable: {e}"

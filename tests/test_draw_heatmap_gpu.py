@@ -464,3 +464,43 @@ def test_dispatch_string_follows_the_public_hints(kernel_variant):
     assert nat.last_dispatch().startswith("splat_kernel<PX=1,R=8,CLEAR=0,SM=0>")
     with pytest.raises(RuntimeError):
         draw_heatmap_batched(hm, rb(c, n), rb(r, n), tile_rows=12)
+
+
+def test_time_next_launch_brackets_one_kernel_and_is_one_shot():
+    """accv_draw_heatmap_time_next_launch: the next splat launch of this thread carries start/stop events (same kernel, same
+    result), the one after it does not"""
+    import ctypes
+
+    from accvlab import _amd_native as nat
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+    hip.hipEventQuery.argtypes = [ctypes.c_void_p]
+    hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+    ev = []
+    for _ in range(2):
+        e = ctypes.c_void_p()
+        assert hip.hipEventCreate(ctypes.byref(e)) == 0
+        ev.append(e.value)
+    _, draw_heatmap_batched = _dh()
+    c = torch.tensor([[[10, 10], [200, 50]], [[100, 30], [5, 90]]], dtype=torch.int32)
+    r = torch.tensor([[3, 20], [5, 7]], dtype=torch.int32)
+    sizes = torch.tensor([2, 2])
+    cd, rd, sd = c.to(DEV), r.to(DEV), sizes.to(DEV)
+    want = torch.empty(2, 96, 256, device=DEV)
+    draw_heatmap_batched(want, rb(cd, sd), rb(rd, sd), clear=True)
+    got = torch.empty_like(want)
+    nat.check(nat.lib().accv_draw_heatmap_time_next_launch(ev[0], ev[1]), "time_next_launch")
+    draw_heatmap_batched(got, rb(cd, sd), rb(rd, sd), clear=True)
+    torch.cuda.synchronize()
+    ms = ctypes.c_float(-1.0)
+    assert hip.hipEventElapsedTime(ctypes.byref(ms), ev[0], ev[1]) == 0 and 0.0 < ms.value < 50.0
+    assert torch.equal(got, want)
+    # one-shot: a further launch leaves the recorded interval untouched
+    draw_heatmap_batched(got, rb(cd, sd), rb(rd, sd), clear=True)
+    torch.cuda.synchronize()
+    ms2 = ctypes.c_float(-1.0)
+    assert hip.hipEventElapsedTime(ctypes.byref(ms2), ev[0], ev[1]) == 0 and ms2.value == ms.value
+    for e in ev:
+        hip.hipEventDestroy(e)
