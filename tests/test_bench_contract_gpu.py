@@ -1,0 +1,48 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (metric / value / unit / n_gpus / steps / warmup /
+ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus `roofline` and `cpu_baseline`.
+Run in-process on a reduced step count (the product path and the oracle leg are the real ones)."""
+import io
+import json
+import sys
+from contextlib import redirect_stdout
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_bench(monkeypatch, *argv):
+    import bench
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", *argv])
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(var, raising=False)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.main()
+    lines = [l for l in buf.getvalue().splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line"
+    return json.loads(lines[0])
+
+
+def test_bench_line_has_the_contract_fields(monkeypatch):
+    d = _run_bench(monkeypatch, "--gpus", "1", "--steps", "20", "--warmup", "5", "--batch", "8")
+    assert d["metric"].startswith("heatmap frames/sec") and d["unit"] == "frames/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["kernel"].startswith("splat_kernel<PX=4,R=8,CLEAR=1,SM=0>")
+    assert r["algorithmic_bytes"] == 8 * 1080 * 1920 * 4 + 12 * d["config"]["objects_per_gpu"] + 4 * 8
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.02            # kernel time cannot exceed the wall time of a step
+    assert r["traffic"] is None or r["traffic"] > 0              # quoted only for the matching instantiation at the bench batch
+    assert 0 < r["kernel_ms_spaced_launches"] < 2 * r["kernel_ms"]
+    assert r["trace_index"]["timed_region_launches"] == 20
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
+    assert "inplace" in d["secondary"] and "rule_B" in d["secondary"]
