@@ -264,31 +264,43 @@ def main():
     sync = torch.cuda.synchronize
     for _ in range(args.warmup):
         step()
+    # the box's clock / power state, sampled with work in the queue.  The sysfs reads take ~0.1 s during which the queue runs
+    # dry, so this comes BEFORE the pre-warm, never between the pre-warm and the timed region
+    env = None
+    if rank == 0:
+        for _ in range(300):
+            step()
+        env = device_env(dev_index)
     # extra untimed pre-warm: the chip needs ~15 ms of back-to-back launches after an idle/sync before kernel times
-    # settle (profiles/r01_rocprof: 109 -> 128 -> 97 us); keep the queue full for >= 100 ms before timing
+    # settle (profiles/r01_rocprof: 109 -> 128 -> 97 us); keep the queue full for >= 100 ms right up to the timed region
     sync()
     t_pre = time.perf_counter()
-    env = None
     while time.perf_counter() - t_pre < 0.1:
         for _ in range(50):
             step()
-        if env is None and rank == 0 and time.perf_counter() - t_pre > 0.05:
-            env = device_env(dev_index)     # sampled under load, outside the timed region
         sync()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e_first = torch.cuda.Event(enable_timing=True)
     trace_index = {"timed_region_launches": args.steps}
 
     def timed_step_region():
         # HIP events on the CURRENT stream = the stream the kernel is launched on; recorded inside the barrier bracket
         trace_index["timed_region_first_launch"] = launches[0]
         e0.record()
-        for _ in range(args.steps):
+        for i in range(args.steps):
             step()
+            if i == 0:
+                e_first.record()
         e1.record()
 
     # exactly K steps between barrier + synchronize brackets; wall clock of this rank, MAX over ranks below
     wall_ms = sharding.timed_steps(timed_step_region, 1, dist=dist, sync=sync) / args.steps
-    kern_ms = e0.elapsed_time(e1) / args.steps       # HIP events around the K back-to-back launches of the timed region
+    # Kernel duration from the events of the timed region.  The opening bracket leaves the GPU idle, and the first launch only
+    # starts once the host has pushed it through (tens of microseconds that belong to no kernel: with K = 20 they inflate
+    # (e1 - e0) / K by 3-5 %, profiles/r02_k20_trace.log).  From the end of launch 1 to the end of launch K the stream runs
+    # back to back, so launches 2..K give the duration of a launch in the timed region; (e1 - e0) / K is reported beside it.
+    region_ms = e0.elapsed_time(e1) / args.steps
+    kern_ms = e_first.elapsed_time(e1) / (args.steps - 1) if args.steps > 1 else region_ms
     kernel = nat.last_dispatch()
     # for information: the same kernel timed launch by launch with start/stop events on the kernel itself (hipExtLaunchKernel
     # through accv_draw_heatmap_time_next_launch), K further launches behind the timed region.  Those events cost ~4 us of
@@ -300,6 +312,7 @@ def main():
     red_dev = dev if backend == "nccl" else None
     wall_ms = sharding.max_over_ranks(wall_ms, device=red_dev)
     kern_ms = sharding.max_over_ranks(kern_ms, device=red_dev)
+    region_ms = sharding.max_over_ranks(region_ms, device=red_dev)
 
     # secondary, rank 0 only: rule B, the reference's exact in-place semantics, and the streaming-write ceiling
     extra = {}
@@ -385,6 +398,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": kernel, "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
+                     "kernel_ms_source": "HIP events on the launch stream inside the timed region: end of launch 1 -> end of "
+                                         "launch K, divided by K - 1 (back-to-back launches)",
+                     "timed_region_event_ms_per_step": region_ms,
                      "kernel_ms_spaced_launches": isolated_ms, "kernel_ms_spaced_launches_note": isolated_note,
                      "trace_index": trace_index},
         "work": wc,

@@ -39,6 +39,7 @@ def test_bench_line_has_the_contract_fields(monkeypatch):
     assert r["algorithmic_bytes"] == 8 * 1080 * 1920 * 4 + 12 * d["config"]["objects_per_gpu"] + 4 * 8
     assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.02            # kernel time cannot exceed the wall time of a step
+    assert r["kernel_ms"] <= r["timed_region_event_ms_per_step"] * 1.02 and "launch K" in r["kernel_ms_source"]
     assert r["traffic"] is None or r["traffic"] > 0              # quoted only for the matching instantiation at the bench batch
     assert 0 < r["kernel_ms_spaced_launches"] < 2 * r["kernel_ms"]
     assert r["trace_index"]["timed_region_launches"] == 20
