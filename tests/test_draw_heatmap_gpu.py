@@ -504,3 +504,16 @@ def test_time_next_launch_brackets_one_kernel_and_is_one_shot():
     assert hip.hipEventElapsedTime(ctypes.byref(ms2), ev[0], ev[1]) == 0 and ms2.value == ms.value
     for e in ev:
         hip.hipEventDestroy(e)
+
+
+@pytest.mark.parametrize("clear", [True, False])
+def test_classwise_call_without_object_slots(clear):
+    """labels of shape [B, 0] have no storage (null data pointer): a class-wise call with Nmax == 0 must not be rejected —
+    it clears (clear=True) or leaves (in-place) the planes, as the reference's launch over zero targets does"""
+    _, draw_heatmap_batched = _dh()
+    hm = torch.full((2, 3, 16, 64), 0.25, device=DEV)
+    c = torch.zeros((2, 0, 2), dtype=torch.int32, device=DEV)
+    r = torch.zeros((2, 0), dtype=torch.int32, device=DEV)
+    n = torch.zeros(2, dtype=torch.int64, device=DEV)
+    draw_heatmap_batched(hm, rb(c, n), rb(r, n), labels=rb(torch.zeros((2, 0), dtype=torch.int32, device=DEV), n), clear=clear)
+    assert float(hm.min()) == float(hm.max()) == (0.0 if clear else 0.25)

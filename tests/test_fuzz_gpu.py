@@ -1,0 +1,201 @@
+"""Seeded random sweeps of the HIP path against the CPU oracle over geometry that the hand-written cases do not enumerate:
+odd map sizes, objects far outside the frame, zero / huge / negative radii, negative k, sparse and dense counts, int32 and
+int64 counts, every public dispatch hint; ragged gathers / scatters / compactions of random shapes and dtypes.
+Tolerance: 1e-5 absolute on heat-map values (north_star), bit-exact on everything that moves bytes or produces indices."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import h1 as oracle
+from oracle import h2 as oracle_h2
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def rb(t, sizes):
+    return SimpleNamespace(tensor=t, sample_sizes=sizes)
+
+
+def _random_h1_case(rng):
+    h = int(rng.choice([1, 2, 7, 15, 16, 17, 33, 64, 100, 129, 250]))
+    w = int(rng.choice([1, 3, 4, 5, 8, 30, 64, 124, 128, 132, 260, 516]))
+    b = int(rng.integers(1, 5))
+    n_max = int(rng.choice([0, 1, 2, 5, 63, 64, 65, 130]))
+    counts = rng.integers(-2, n_max + 3, size=b)
+    span = max(h, w)
+    cx = rng.integers(-span, w + span, size=(b, n_max))
+    cy = rng.integers(-span, h + span, size=(b, n_max))
+    kind = rng.integers(0, 10, size=(b, n_max))
+    radii = rng.integers(0, 12, size=(b, n_max))
+    radii = np.where(kind == 0, rng.integers(0, 4 * span + 2, size=(b, n_max)), radii)      # huge
+    radii = np.where(kind == 1, -rng.integers(1, 5, size=(b, n_max)), radii)                # negative: never drawn
+    radii = np.where(kind == 2, 0, radii)
+    centers = np.stack([cx, cy], -1).astype(np.int32)
+    return h, w, b, n_max, counts, centers, radii.astype(np.int32)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_h1_random_geometry_against_the_oracle(seed):
+    from accvlab import _amd_native as nat
+    from accvlab.draw_heatmap import draw_heatmap_batched, ops
+
+    rng = np.random.default_rng(1000 + seed)
+    hints = [0, nat.HM_TILE_ROWS_16, nat.HM_SMALL_RADII, nat.HM_WRITE_THROUGH, nat.HM_PLAIN_STORES,
+             nat.HM_TILE_ROWS_16 | nat.HM_WRITE_THROUGH]
+    for case in range(10):
+        h, w, b, n_max, counts, centers, radii = _random_h1_case(rng)
+        k = float(rng.choice([1.0, 0.8, -0.5, 2.0]))
+        factor = float(rng.choice([3.0, 6.0, 12.0]))
+        clear = bool(rng.integers(0, 2))
+        classwise = bool(rng.integers(0, 3) == 0)
+        ncls = int(rng.integers(1, 4)) if classwise else 0
+        labels = rng.integers(-1, ncls + 1, size=(b, n_max)).astype(np.int32) if classwise else None
+        counts_t = torch.from_numpy(counts.astype(np.int32 if case % 2 else np.int64))
+        shape = (b, ncls, h, w) if classwise else (b, h, w)
+        base = (rng.random(shape, dtype=np.float32) - 0.3).astype(np.float32)
+        want = base.copy()
+        oracle.draw_heatmap_batched(want, centers, radii, np.clip(counts, 0, n_max), labels=labels, factor=factor, k=k, clear=clear)
+        got = torch.from_numpy(base.copy()).to(DEV)
+        c_t, r_t, n_t = torch.from_numpy(centers).to(DEV), torch.from_numpy(radii).to(DEV), counts_t.to(DEV)
+        ops._FORCED_FLAGS = hints[(seed + case) % len(hints)]
+        try:
+            draw_heatmap_batched(got, rb(c_t, n_t), rb(r_t, n_t), factor, k,
+                                 labels=rb(torch.from_numpy(labels).to(DEV), n_t) if classwise else None, clear=clear)
+        finally:
+            ops._FORCED_FLAGS = 0
+        err = float(np.abs(got.cpu().numpy().astype(np.float64) - want.astype(np.float64)).max()) if want.size else 0.0
+        assert err <= 1e-5, f"seed {seed} case {case}: {shape}, n_max {n_max}, clear {clear}, k {k}: max abs err {err}"
+
+
+# the dtype set of the reference's gather / scatter dispatch (batched_indexing_access_helpers.h:60-100); compaction takes more
+_DTYPES = [torch.float32, torch.float16, torch.int64, torch.int32, torch.float64, torch.bfloat16]
+_MASK_DTYPES = _DTYPES + [torch.uint8, torch.bool]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_h2_random_gather_scatter_compaction_against_the_oracle(seed):
+    from accvlab.batching_helpers import RaggedBatch, batched_bool_indexing, batched_indexing_access, \
+        batched_inverse_indexing_access, get_indices_from_mask
+
+    rng = np.random.default_rng(2000 + seed)
+    for case in range(6):
+        b = int(rng.integers(1, 6))
+        n_src = int(rng.choice([1, 2, 7, 64, 65, 200]))
+        n_idx = int(rng.choice([0, 1, 3, 33, 64, 130]))
+        inner = tuple(int(x) for x in rng.choice([1, 2, 3, 4, 8, 17], size=int(rng.integers(0, 3))))
+        dt = _DTYPES[(seed + case) % len(_DTYPES)]
+        data = (torch.rand((b, n_src) + inner) * 100).to(dt)
+        idx = torch.from_numpy(rng.integers(-n_src, n_src, size=(b, n_idx)))
+        counts = torch.from_numpy(rng.integers(0, n_idx + 1, size=b))
+        fill = 7
+        # gather
+        got = batched_indexing_access(data.to(DEV), RaggedBatch(idx.to(DEV), sample_sizes=counts.to(DEV)), fill)
+        want = oracle_h2.gather(data.view(torch.int16).numpy() if dt == torch.bfloat16 else data.numpy(), idx.numpy(), counts.numpy(),
+                                torch.tensor(fill, dtype=dt).view(torch.int16).item() if dt == torch.bfloat16 else fill)
+        g = got.tensor.cpu()
+        assert np.array_equal(g.view(torch.int16).numpy() if dt == torch.bfloat16 else g.numpy(), want), f"gather seed {seed} case {case}"
+        # inverse (scatter into a fresh tensor): unique indices so that the result does not depend on write order
+        n_tgt = n_src + 3
+        perm = np.stack([rng.permutation(n_tgt)[:n_idx] if n_idx <= n_tgt else np.resize(rng.permutation(n_tgt), n_idx) for _ in range(b)])
+        if n_idx <= n_tgt:
+            src = (torch.rand((b, n_idx) + inner) * 50).to(dt)
+            got = batched_inverse_indexing_access(RaggedBatch(src.to(DEV), sample_sizes=counts.to(DEV)),
+                                                  RaggedBatch(torch.from_numpy(perm).to(DEV), sample_sizes=counts.to(DEV)), n_tgt, fill)
+            want = oracle_h2.scatter_new(src.view(torch.int16).numpy() if dt == torch.bfloat16 else src.numpy(), perm, counts.numpy(), n_tgt,
+                                         torch.tensor(fill, dtype=dt).view(torch.int16).item() if dt == torch.bfloat16 else fill, False)
+            g = (got.tensor if hasattr(got, "tensor") else got).cpu()
+            assert np.array_equal(g.view(torch.int16).numpy() if dt == torch.bfloat16 else g.numpy(), want), f"inverse seed {seed} case {case}"
+        # compaction by mask + indices from mask
+        mask = torch.from_numpy(rng.random((b, n_src)) < rng.random())
+        dt = _MASK_DTYPES[(seed + case) % len(_MASK_DTYPES)]
+        data = (torch.rand((b, n_src) + inner) * 100).to(dt) if dt != torch.bool else torch.rand((b, n_src) + inner) > 0.5
+        comp = batched_bool_indexing(data.to(DEV), mask.to(DEV))
+        want_rows, want_sizes = oracle_h2.bool_compact(data.view(torch.int16).numpy() if dt == torch.bfloat16 else data.numpy(), mask.numpy())
+        assert np.array_equal(comp.sample_sizes.cpu().numpy(), want_sizes)
+        c = comp.tensor.cpu()
+        c = c.view(torch.int16).numpy() if dt == torch.bfloat16 else c.numpy()
+        for i in range(b):
+            assert np.array_equal(c[i, : want_sizes[i]], want_rows[i][: want_sizes[i]]), f"compaction seed {seed} case {case} sample {i}"
+        ind = get_indices_from_mask(mask.to(DEV))
+        want_idx, want_cnt = oracle_h2.indices_from_mask(mask.numpy())
+        assert np.array_equal(ind.sample_sizes.cpu().numpy(), want_cnt)
+        for i in range(b):
+            assert np.array_equal(ind.tensor[i, : want_cnt[i]].cpu().numpy(), want_idx[i][: want_cnt[i]])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_h1_flat_api_random_planes_against_the_oracle(seed):
+    """draw_heatmap (flat input): random plane indices incl. out-of-range ones (ignored), empty planes, N below and above the
+    single-launch binning limit"""
+    from accvlab.draw_heatmap import draw_heatmap
+
+    rng = np.random.default_rng(3000 + seed)
+    for case in range(6):
+        p = int(rng.choice([1, 2, 5, 33, 300]))
+        h = int(rng.choice([1, 9, 32, 100]))
+        w = int(rng.choice([4, 30, 64, 260]))
+        n = int(rng.choice([0, 1, 7, 200, 3000]))
+        centers = np.stack([rng.integers(-20, w + 20, size=n), rng.integers(-20, h + 20, size=n)], -1).astype(np.int32)
+        radii = rng.integers(-1, 15, size=n).astype(np.int32)
+        idx = rng.integers(-2, p + 2, size=n).astype(np.int32)
+        k = float(rng.choice([1.0, 0.7]))
+        base = (rng.random((p, h, w), dtype=np.float32) * 0.4).astype(np.float32)
+        want = base.copy()
+        oracle.draw_heatmap_flat(want, centers, radii, idx, 6.0, k)
+        got = torch.from_numpy(base.copy()).to(DEV)
+        draw_heatmap(got, torch.from_numpy(centers).to(DEV), torch.from_numpy(radii).to(DEV), torch.from_numpy(idx).to(DEV), 6.0, k)
+        err = float(np.abs(got.cpu().numpy().astype(np.float64) - want.astype(np.float64)).max()) if want.size else 0.0
+        assert err <= 1e-5, f"seed {seed} case {case}: P {p} {h}x{w} N {n}: max abs err {err}"
+
+
+def _random_tree(rng, depth=0):
+    kinds = ["tensor"] * 5 + ["list", "dict", "tuple", "other"] if depth < 3 else ["tensor", "other"]
+    kind = kinds[int(rng.integers(0, len(kinds)))]
+    if kind == "tensor":
+        dt = [torch.float32, torch.int64, torch.float16, torch.uint8, torch.bool, torch.complex64, torch.float64][int(rng.integers(0, 7))]
+        shape = tuple(int(x) for x in rng.integers(0, 9, size=int(rng.integers(0, 4))))
+        t = (torch.rand(shape) * 50).to(dt) if dt not in (torch.bool, torch.complex64) else \
+            (torch.rand(shape) > 0.5 if dt == torch.bool else torch.complex(torch.rand(shape), torch.rand(shape)))
+        if shape and rng.integers(0, 6) == 0 and t.dim() >= 2:
+            t = t.transpose(0, -1)            # non-contiguous leaf
+        return t
+    if kind == "other":
+        return [None, 3, "text", 2.5][int(rng.integers(0, 4))]
+    n = int(rng.integers(0, 5))
+    items = [_random_tree(rng, depth + 1) for _ in range(n)]
+    if kind == "list":
+        return items
+    if kind == "tuple":
+        return tuple(items)
+    return {f"k{i}": v for i, v in enumerate(items)}
+
+
+def _same(a, b):
+    if isinstance(a, torch.Tensor):
+        return isinstance(b, torch.Tensor) and a.dtype == b.dtype and a.shape == b.shape and torch.equal(a.cpu(), b.cpu())
+    if isinstance(a, (list, tuple)):
+        return type(a) is type(b) and len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, dict):
+        return isinstance(b, dict) and list(a) == list(b) and all(_same(a[k], b[k]) for k in a)
+    return a is b or a == b
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_h3_random_trees_round_trip_bit_exact(seed):
+    """start_copy over random nestings / dtypes / empty and non-contiguous leaves, to the GPU and back, both modes, several
+    packing parameters: structure, dtypes, shapes and bytes are preserved"""
+    from accvlab.multi_tensor_copier import start_copy
+
+    rng = np.random.default_rng(4000 + seed)
+    for case in range(5):
+        tree = [_random_tree(rng) for _ in range(int(rng.integers(1, 12)))]
+        kw = dict(use_background_thread=bool(rng.integers(0, 2)), pack_cpu_tensors=bool(rng.integers(0, 4) > 0),
+                  min_packed_alignment_bytes=int(rng.choice([1, 6, 16, 64])), max_packed_chunk_bytes=int(rng.choice([256, 4096, 32 << 20])),
+                  use_pinned_staging=bool(rng.integers(0, 4) > 0))
+        on_gpu = start_copy(tree, DEV, **kw).get()
+        assert _same(tree, on_gpu), f"seed {seed} case {case} {kw}: host -> GPU"
+        back = start_copy(on_gpu, "cpu", **kw).get()
+        assert _same(tree, back), f"seed {seed} case {case} {kw}: GPU -> host"
