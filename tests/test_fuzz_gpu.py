@@ -199,3 +199,57 @@ def test_h3_random_trees_round_trip_bit_exact(seed):
         assert _same(tree, on_gpu), f"seed {seed} case {case} {kw}: host -> GPU"
         back = start_copy(on_gpu, "cpu", **kw).get()
         assert _same(tree, back), f"seed {seed} case {case} {kw}: GPU -> host"
+
+
+def _np(t):
+    t = t.cpu()
+    return t.view(torch.int16).numpy() if t.dtype == torch.bfloat16 else t.numpy()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_h2_random_write_mapping_mask_padfill_boolwrite_against_the_oracle(seed):
+    """the writing half of batching_helpers: indexing write, index mapping, mask from indices, pad fill, boolean write-back —
+    random shapes, dtypes, negative (wrapping) indices, ragged masks"""
+    from accvlab.batching_helpers import RaggedBatch, batched_bool_indexing_write, batched_index_mapping, \
+        batched_indexing_write, get_mask_from_indices
+
+    rng = np.random.default_rng(5000 + seed)
+    for case in range(6):
+        b = int(rng.integers(1, 6))
+        n_tgt = int(rng.choice([1, 3, 64, 65, 150]))
+        n_src = int(rng.choice([1, 5, 70]))
+        n_idx = int(rng.choice([0, 1, 4, 40])) if n_tgt >= 40 else int(rng.integers(0, n_tgt + 1))
+        n_idx = min(n_idx, n_tgt)
+        inner = tuple(int(x) for x in rng.choice([1, 2, 5, 16], size=int(rng.integers(0, 3))))
+        dt = _DTYPES[(seed + case) % len(_DTYPES)]
+        counts = torch.from_numpy(rng.integers(0, n_idx + 1, size=b))
+        # unique target indices per sample, half of them written as negative (wrap once, cu:75-77)
+        tgt = np.stack([rng.permutation(n_tgt)[:n_idx] for _ in range(b)]).reshape(b, n_idx).astype(np.int64)
+        tgt = np.where(rng.random(tgt.shape) < 0.5, tgt - n_tgt, tgt)
+        src_idx = rng.integers(-n_src, n_src, size=(b, n_idx)).astype(np.int64)
+        into = (torch.rand((b, n_tgt) + inner) * 90).to(dt)
+        vals = (torch.rand((b, n_idx) + inner) * 90).to(dt)
+        src = (torch.rand((b, n_src) + inner) * 90).to(dt)
+        tgt_rb = RaggedBatch(torch.from_numpy(tgt).to(DEV), sample_sizes=counts.to(DEV))
+        got = batched_indexing_write(RaggedBatch(vals.to(DEV), sample_sizes=counts.to(DEV)), tgt_rb, into.to(DEV))
+        assert np.array_equal(_np(got), oracle_h2.scatter_insert(_np(vals), tgt, counts.numpy(), _np(into))), f"write {seed}/{case}"
+        got = batched_index_mapping(src.to(DEV), RaggedBatch(torch.from_numpy(src_idx).to(DEV), sample_sizes=counts.to(DEV)), tgt_rb,
+                                    into.to(DEV))
+        assert np.array_equal(_np(got), oracle_h2.map_pairs(_np(src), src_idx, tgt, counts.numpy(), _np(into))), f"mapping {seed}/{case}"
+        got = get_mask_from_indices(n_tgt, tgt_rb)
+        assert np.array_equal(got.cpu().numpy(), oracle_h2.mask_from_indices(tgt, counts.numpy(), n_tgt)), f"mask {seed}/{case}"
+        # pad fill through the RaggedBatch method, bool write-back through a ragged mask
+        sizes = torch.from_numpy(rng.integers(0, n_tgt + 1, size=b))
+        filled = RaggedBatch(into.clone().to(DEV), sample_sizes=sizes.to(DEV)).with_padded_set_to(3)
+        want = oracle_h2.pad_fill(_np(into), sizes.numpy(), torch.tensor(3, dtype=dt).view(torch.int16).item() if dt == torch.bfloat16 else 3)
+        assert np.array_equal(_np(filled.tensor), want), f"pad fill {seed}/{case}"
+        mask = torch.from_numpy(rng.random((b, n_tgt)) < 0.4)
+        valid = sizes
+        n_true = np.array([int(mask[i, : int(valid[i])].sum()) for i in range(b)])
+        wsz = torch.from_numpy(np.array([int(rng.integers(0, n_true[i] + 1)) if rng.integers(0, 2) else n_true[i] for i in range(b)]))
+        width = int(max(int(n_true.max()) if b else 0, 1))
+        to_write = (torch.rand((b, width) + inner) * 90).to(dt)
+        got = batched_bool_indexing_write(RaggedBatch(to_write.to(DEV), sample_sizes=wsz.to(DEV)),
+                                          RaggedBatch(mask.to(DEV), sample_sizes=valid.to(DEV)), into.to(DEV))
+        want = oracle_h2.bool_write(_np(to_write), wsz.numpy(), mask.numpy(), _np(into), valid.numpy())
+        assert np.array_equal(_np(got.tensor if hasattr(got, "tensor") else got), want), f"bool write {seed}/{case}"
