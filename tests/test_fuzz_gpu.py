@@ -253,3 +253,43 @@ def test_h2_random_write_mapping_mask_padfill_boolwrite_against_the_oracle(seed)
                                           RaggedBatch(mask.to(DEV), sample_sizes=valid.to(DEV)), into.to(DEV))
         want = oracle_h2.bool_write(_np(to_write), wsz.numpy(), mask.numpy(), _np(into), valid.numpy())
         assert np.array_equal(_np(got.tensor if hasattr(got, "tensor") else got), want), f"bool write {seed}/{case}"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_lane_sampler_random_polylines_against_the_oracle(seed):
+    """interpolate / lengths (fixed and ragged): random point counts incl. 0 and 1, repeated points (zero-length segments),
+    queries before the start and beyond the end, relative mode, 2-D and 3-D points.  atol 1e-5 relative to the polyline scale
+    (packages/lane_helpers/tests/polyline_test_utils.py:78-115 uses atol=1e-5 on unit-scale data)."""
+    from oracle import lane as oracle_lane
+
+    from accvlab.batching_helpers import RaggedBatch
+    from accvlab.lane_helpers.polyline import interpolate_var_size_batch, lengths_var_size_batch
+
+    rng = np.random.default_rng(6000 + seed)
+    for case in range(5):
+        b = int(rng.integers(1, 7))
+        p_max = int(rng.choice([1, 2, 5, 24, 70]))
+        q_max = int(rng.choice([1, 3, 64, 130]))
+        dims = int(rng.choice([2, 3]))
+        relative = bool(rng.integers(0, 2))
+        pts = rng.random((b, p_max, dims)).astype(np.float32) * 4.0
+        dup = rng.random((b, p_max)) < 0.15                     # repeated points: zero-length segments
+        for i in range(b):
+            for j in range(1, p_max):
+                if dup[i, j]:
+                    pts[i, j] = pts[i, j - 1]
+        n_pts = rng.integers(0, p_max + 1, size=b)
+        n_q = rng.integers(0, q_max + 1, size=b)
+        dist = (rng.random((b, q_max)).astype(np.float32) * 1.4 - 0.2) * (1.0 if relative else 6.0)
+        got = interpolate_var_size_batch(RaggedBatch(torch.from_numpy(pts).to(DEV), sample_sizes=torch.from_numpy(n_pts).to(DEV)),
+                                         RaggedBatch(torch.from_numpy(dist).to(DEV), sample_sizes=torch.from_numpy(n_q).to(DEV)),
+                                         relative=relative)
+        g = got.tensor.cpu().numpy()
+        lens = lengths_var_size_batch(RaggedBatch(torch.from_numpy(pts).to(DEV), sample_sizes=torch.from_numpy(n_pts).to(DEV))).cpu().numpy()
+        for i in range(b):
+            want = oracle_lane.sample(pts[i, : n_pts[i]], dist[i, : n_q[i]], relative)
+            have = g[i, : n_q[i]]
+            assert np.array_equal(np.isnan(have), np.isnan(want)), f"lane {seed}/{case} sample {i}: NaN pattern"
+            assert np.allclose(have, want, atol=4e-5, rtol=0, equal_nan=True), f"lane {seed}/{case} sample {i}"
+            wl_ = oracle_lane.length(pts[i, : n_pts[i]])
+            assert (np.isnan(wl_) and np.isnan(lens[i])) or abs(lens[i] - wl_) <= 4e-5, f"lane length {seed}/{case} sample {i}"
