@@ -293,3 +293,30 @@ def test_lane_sampler_random_polylines_against_the_oracle(seed):
             assert np.allclose(have, want, atol=4e-5, rtol=0, equal_nan=True), f"lane {seed}/{case} sample {i}"
             wl_ = oracle_lane.length(pts[i, : n_pts[i]])
             assert (np.isnan(wl_) and np.isnan(lens[i])) or abs(lens[i] - wl_) <= 4e-5, f"lane length {seed}/{case} sample {i}"
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_wide_mask_compaction_random_against_the_oracle(seed):
+    """mask -> indices on the one-wave, the multi-wave and the segmented (two-pass, >= 8192 columns) paths: random widths that
+    are no multiples of the segment size, random densities incl. all-False / all-True rows, ragged validity"""
+    from accvlab.batching_helpers import RaggedBatch, get_indices_from_mask
+
+    rng = np.random.default_rng(7000 + seed)
+    for case in range(5):
+        b = int(rng.integers(1, 10))
+        w = int(rng.choice([1, 63, 64, 65, 511, 513, 4095, 4097, 8191, 8192, 8193, 12289, 40001, 70000]))
+        dens = rng.random(b) * rng.choice([0.0, 0.02, 0.5, 1.0])
+        mask = rng.random((b, w)) < dens[:, None]
+        if b > 1:
+            mask[0] = True
+            mask[-1] = False
+        valid = rng.integers(0, w + 1, size=b)
+        ragged = bool(rng.integers(0, 2))
+        m = torch.from_numpy(mask).to(DEV)
+        got = get_indices_from_mask(RaggedBatch(m, sample_sizes=torch.from_numpy(valid).to(DEV)) if ragged else m)
+        want_idx, want_cnt = oracle_h2.indices_from_mask(mask, valid if ragged else None)
+        assert np.array_equal(got.sample_sizes.cpu().numpy(), want_cnt), f"counts {seed}/{case} w {w}"
+        g = got.tensor.cpu().numpy()
+        assert g.shape[1] == (int(want_cnt.max()) if b else 0)
+        for i in range(b):
+            assert np.array_equal(g[i, : want_cnt[i]], want_idx[i][: want_cnt[i]]), f"indices {seed}/{case} w {w} row {i}"
