@@ -431,7 +431,8 @@ class RaggedBatch:
         data = src.tensor
         sizes = host_sizes(src.sample_sizes)     # no device read-back when the sizes came from the host (combine_data)
         back = self._non_uniform_dim - nb
-        flat = data.reshape(-1, *data.shape[nb:]) if nb > 1 else data
+        # (explicit batch extent: reshape(-1, ...) is ambiguous when every sample is empty and the tensor has no elements)
+        flat = data.reshape(math.prod(data.shape[:nb]), *data.shape[nb:]) if nb > 1 else data
         width = flat.shape[1] if flat.dim() > 1 else 0
 
         if _bh is not None and flat.dim() > 1:
