@@ -317,6 +317,13 @@ class RaggedBatch:
         """Reshape the batch dimensions (``-1`` allowed); the non-uniform dimension index follows."""
         new_batch_shape = _as_tuple(new_batch_shape)
         nb = self._num_batch_dims
+        if new_batch_shape.count(-1) == 1:
+            # resolve the free extent from the number of samples: with every sample empty the tensor has no elements and
+            # torch cannot infer it (the same reshape in the reference raises there, ragged_batch.py:697)
+            known = -math.prod(new_batch_shape)
+            total = math.prod(self._batch_shape)
+            if known > 0 and total % known == 0:
+                new_batch_shape = tuple(total // known if e == -1 else e for e in new_batch_shape)
         tensor = self._tensor.reshape(*new_batch_shape, *self._tensor.shape[nb:])
         mask = self._mask.reshape(*new_batch_shape, self._mask.shape[-1]) if self._mask is not None else None
         sizes = self._sample_sizes.reshape(*new_batch_shape) if self._sample_sizes is not None else None

@@ -82,3 +82,97 @@ def test_cpu_compaction_random_against_the_oracle(seed):
         idx = get_indices_from_mask(mask)
         want_idx, want_cnt = oracle_h2.indices_from_mask(mask.numpy())
         assert np.array_equal(idx.sample_sizes.numpy(), want_cnt) and np.array_equal(idx.tensor.numpy()[:, : want_idx.shape[1]], want_idx)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# model-based sweep of RaggedBatch's shape operations: the model of a batch is the nested list of its samples' valid
+# entries (what split() returns); every operation has an obvious meaning on that list
+def _leaves(nested, depth):
+    return [nested] if depth == 0 else [l for sub in nested for l in _leaves(sub, depth - 1)]
+
+
+def _random_ragged(rng, nb=None):
+    from accvlab.batching_helpers import RaggedBatch
+
+    nb = int(rng.integers(1, 4)) if nb is None else nb
+    batch_shape = tuple(int(x) for x in rng.integers(1, 4, size=nb))
+    n_data = int(rng.integers(1, 4))                      # data dims incl. the non-uniform one
+    nu_pos = int(rng.integers(0, n_data))
+    data_shape = [int(x) for x in rng.integers(1, 4, size=n_data)]
+    sizes = rng.integers(0, 5, size=batch_shape)
+    longest = int(sizes.max())
+    data_shape[nu_pos] = longest
+    t = torch.from_numpy(rng.random(batch_shape + tuple(data_shape)))
+    nu = nb + nu_pos
+    # junk in the padding must never be visible through split()
+    return RaggedBatch(t, sample_sizes=torch.from_numpy(sizes), non_uniform_dim=nu), nb, nu_pos
+
+
+def _model(rbatch):
+    nb, nu = rbatch.num_batch_dims, rbatch.non_uniform_dim
+    out = []
+    flat_t = rbatch.tensor.reshape((-1,) + tuple(rbatch.tensor.shape[nb:])) if rbatch.tensor.numel() else None
+    sizes = rbatch.sample_sizes.reshape(-1).tolist()
+    for i, n in enumerate(sizes):
+        if flat_t is None:
+            shape = list(rbatch.tensor.shape[nb:])
+            shape[nu - nb] = 0
+            out.append(torch.zeros(shape, dtype=rbatch.tensor.dtype))
+        else:
+            out.append(flat_t[i].narrow(nu - nb, 0, n))
+    return out
+
+
+def _check(rbatch, want_leaves, want_batch_shape, what):
+    assert tuple(rbatch.batch_shape) == tuple(want_batch_shape), what
+    assert tuple(rbatch.sample_sizes.shape) == tuple(want_batch_shape), what
+    got = _leaves(rbatch.split(), rbatch.num_batch_dims)
+    assert len(got) == len(want_leaves), what
+    for g, w in zip(got, want_leaves):
+        assert tuple(g.shape) == tuple(w.shape) and torch.equal(g, w), what
+    cols = torch.arange(rbatch.tensor.shape[rbatch.non_uniform_dim])
+    assert torch.equal(rbatch.mask, cols < rbatch.sample_sizes.unsqueeze(-1)), what + ": mask"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_ragged_batch_shape_operations_against_the_list_model(seed):
+    rng = np.random.default_rng(9800 + seed)
+    for case in range(8):
+        rbatch, nb, nu_pos = _random_ragged(rng)
+        leaves = _model(rbatch)
+        shape = tuple(rbatch.batch_shape)
+        _check(rbatch, leaves, shape, "identity")
+        # flatten / reshape of the batch dimensions keep the samples in row-major order
+        _check(rbatch.flatten_batch_dims(), leaves, (len(leaves),), "flatten_batch_dims")
+        total = len(leaves)
+        for cand in ((total,), (1, total), (total, 1), shape[::-1]):
+            if int(np.prod(cand)) == total:
+                _check(rbatch.reshape_batch_dims(cand), leaves, cand, f"reshape_batch_dims{cand}")
+        # unsqueeze / squeeze a batch dimension
+        d = int(rng.integers(0, nb + 1))
+        un = rbatch.unsqueeze_batch_dim(d)
+        _check(un, leaves, shape[:d] + (1,) + shape[d:], "unsqueeze_batch_dim")
+        _check(un.squeeze_batch_dim(d), leaves, shape, "squeeze_batch_dim")
+        # move the non-uniform dimension: every sample is transposed accordingly
+        n_data = rbatch.tensor.dim() - nb
+        new_pos = int(rng.integers(0, n_data))
+        moved = rbatch.get_non_uniform_dimension_transposed_to(nb + new_pos)
+        assert moved.non_uniform_dim == nb + new_pos
+        _check(moved, [l.transpose(nu_pos, new_pos) for l in leaves], shape, "get_non_uniform_dimension_transposed_to")
+        # a new data dimension
+        dd = int(rng.integers(nb, rbatch.tensor.dim() + 1))
+        _check(rbatch.unsqueeze_data_dim(dd), [l.unsqueeze(dd - nb) for l in leaves], shape, "unsqueeze_data_dim")
+        # repeat the samples along one batch dimension
+        bd, k = int(rng.integers(0, nb)), int(rng.integers(1, 4))
+        rep = rbatch.repeat_samples(k, bd)
+        idx = np.arange(total).reshape(shape)
+        idx = np.tile(idx, [k if a == bd else 1 for a in range(nb)])
+        _check(rep, [leaves[j] for j in idx.reshape(-1)], idx.shape, "repeat_samples")
+        # padding never leaks: fill it and compare again
+        _check(rbatch.with_padded_set_to(-7.0), leaves, shape, "with_padded_set_to")
+        # existence weights: shaped like the data, 1 for valid entries and 0 in the padding (ragged_batch.py:493-522)
+        w = rbatch.get_existence_weights()
+        t = rbatch.tensor
+        pos = torch.arange(t.shape[rbatch.non_uniform_dim]).reshape([-1 if a == rbatch.non_uniform_dim else 1 for a in range(t.dim())])
+        valid = pos < rbatch.sample_sizes.reshape(tuple(shape) + (1,) * (t.dim() - nb))
+        assert w.shape == t.shape and torch.equal(w, valid.expand(t.shape).to(w.dtype))
