@@ -320,3 +320,74 @@ def test_wide_mask_compaction_random_against_the_oracle(seed):
         assert g.shape[1] == (int(want_cnt.max()) if b else 0)
         for i in range(b):
             assert np.array_equal(g[i, : want_cnt[i]], want_idx[i][: want_cnt[i]]), f"indices {seed}/{case} w {w} row {i}"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ragged_batch_shape_operations_on_the_gpu_against_the_list_model(seed):
+    """the model-based sweep of tests/test_fuzz_cpu.py on GPU tensors (mask and pad-fill kernels, split without read-back)"""
+    import test_fuzz_cpu as m
+
+    rng = np.random.default_rng(9900 + seed)
+    for case in range(6):
+        cpu_batch, nb, nu_pos = m._random_ragged(rng)
+        leaves = m._model(cpu_batch)
+        rbatch = cpu_batch.to_device(DEV)
+        shape = tuple(rbatch.batch_shape)
+
+        def check(rb_, want, want_shape, what):
+            assert tuple(rb_.batch_shape) == tuple(want_shape), what
+            got = m._leaves(rb_.split(), rb_.num_batch_dims)
+            assert len(got) == len(want), what
+            for g, w in zip(got, want):
+                assert g.is_cuda and tuple(g.shape) == tuple(w.shape) and torch.equal(g.cpu(), w), what
+            cols = torch.arange(rb_.tensor.shape[rb_.non_uniform_dim], device=DEV)
+            assert torch.equal(rb_.mask, cols < rb_.sample_sizes.unsqueeze(-1)), what + ": mask"
+
+        check(rbatch, leaves, shape, "identity")
+        check(rbatch.flatten_batch_dims(), leaves, (len(leaves),), "flatten_batch_dims")
+        n_data = rbatch.tensor.dim() - nb
+        new_pos = int(rng.integers(0, n_data))
+        check(rbatch.get_non_uniform_dimension_transposed_to(nb + new_pos), [l.transpose(nu_pos, new_pos) for l in leaves], shape,
+              "get_non_uniform_dimension_transposed_to")
+        bd, k = int(rng.integers(0, nb)), int(rng.integers(1, 4))
+        idx = np.tile(np.arange(len(leaves)).reshape(shape), [k if a == bd else 1 for a in range(nb)])
+        check(rbatch.repeat_samples(k, bd), [leaves[j] for j in idx.reshape(-1)], idx.shape, "repeat_samples")
+        filled = rbatch.with_padded_set_to(-7.0)
+        check(filled, leaves, shape, "with_padded_set_to")
+        t = filled.tensor.cpu()
+        pos = torch.arange(t.shape[filled.non_uniform_dim]).reshape([-1 if a == filled.non_uniform_dim else 1 for a in range(t.dim())])
+        pad = (pos >= cpu_batch.sample_sizes.reshape(shape + (1,) * (t.dim() - nb))).expand(t.shape)
+        assert bool((t[pad] == -7.0).all())
+        check(rbatch.cpu().to_device(DEV), leaves, shape, "cpu -> device round trip")
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_matched_pair_loss_random_against_the_composition(seed):
+    """fused gather + loss + masked sum against the same thing composed from the package's operators (float64 on the host)"""
+    from accvlab.batching_helpers import RaggedBatch, matched_pair_loss_sum
+
+    rng = np.random.default_rng(9950 + seed)
+    for case in range(5):
+        b, na, nbb, d = int(rng.integers(1, 7)), int(rng.choice([1, 9, 100, 300])), int(rng.choice([1, 7, 64])), int(rng.choice([1, 4, 7, 10]))
+        k = int(rng.integers(0, min(na, nbb) + 1))
+        a = torch.from_numpy(rng.standard_normal((b, na, d)).astype(np.float32))
+        bb = torch.from_numpy(rng.standard_normal((b, nbb, d)).astype(np.float32))
+        ia = np.stack([rng.permutation(na)[:k] for _ in range(b)]).reshape(b, k)
+        ib = np.stack([rng.permutation(nbb)[:k] for _ in range(b)]).reshape(b, k)
+        counts = rng.integers(0, k + 1, size=b)
+        kind = ["l1", "l2", "smooth_l1"][(seed + case) % 3]
+        got = matched_pair_loss_sum(a.to(DEV), bb.to(DEV),
+                                    RaggedBatch(torch.from_numpy(ia).to(DEV), sample_sizes=torch.from_numpy(counts).to(DEV)),
+                                    RaggedBatch(torch.from_numpy(ib).to(DEV), sample_sizes=torch.from_numpy(counts).to(DEV)), kind=kind)
+        want = np.zeros(b)
+        for i in range(b):
+            for j in range(counts[i]):
+                diff = a[i, ia[i, j]].double().numpy() - bb[i, ib[i, j]].double().numpy()
+                if kind == "l1":
+                    want[i] += np.abs(diff).sum()
+                elif kind == "l2":
+                    want[i] += (diff * diff).sum()
+                else:
+                    ad = np.abs(diff)
+                    want[i] += np.where(ad < 1.0, 0.5 * diff * diff, ad - 0.5).sum()
+        assert np.allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5), f"matched loss {seed}/{case} {kind}"
