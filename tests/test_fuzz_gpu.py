@@ -391,3 +391,50 @@ def test_matched_pair_loss_random_against_the_composition(seed):
                     ad = np.abs(diff)
                     want[i] += np.where(ad < 1.0, 0.5 * diff * diff, ad - 0.5).sum()
         assert np.allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5), f"matched loss {seed}/{case} {kind}"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_multiscale_and_lane_raster_random_against_the_per_scale_operators(seed):
+    """one-launch multi-scale box maps and lane rasters == the per-scale operators, bit for bit, over random strides, map shapes
+    (incl. ones the fused kernels do not take), counts incl. zero, lanes with few / no points, fused clear and in-place"""
+    from accvlab.batching_helpers import combine_data
+    from accvlab.draw_heatmap import (draw_heatmap_batched, draw_heatmap_multiscale, draw_polylines_batched, draw_polylines_multiscale,
+                                      get_centers_and_radii)
+
+    rng = np.random.default_rng(9970 + seed)
+    for case in range(4):
+        b = int(rng.integers(1, 5))
+        sw, sh = int(rng.choice([64, 200, 512, 1000])), int(rng.choice([32, 96, 300]))
+        n_scales = int(rng.integers(1, 5))
+        strides = [float(x) for x in rng.choice([1.0, 2.0, 3.0, 4.0, 5.0, 8.0, 16.0], size=n_scales, replace=False)]
+        clear = bool(rng.integers(0, 2))
+        g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+        cs, bs = [], []
+        for _ in range(b):
+            n = int(rng.integers(0, 20))
+            c = torch.rand(n, 2, generator=g) * torch.tensor([sw, sh])
+            half = torch.rand(n, 4, generator=g) * min(sw, sh) * 0.3
+            cs.append(c)
+            bs.append(torch.cat([c - half[:, :2], c + half[:, 2:]], 1))
+        crb = combine_data(cs, device=DEV)
+        brb = combine_data(bs, device=DEV, other_with_same_sample_sizes=crb)
+        shapes = [(b, max(1, int(sh / s)), max(1, int(sw / s))) for s in strides]
+        base = [(torch.rand(s_, generator=g) * 0.3).to(DEV) for s_ in shapes]
+        fused = [t.clone() for t in base]
+        draw_heatmap_multiscale(fused, crb, brb, strides, 6.0, 0.9, clear=clear)
+        for i, s in enumerate(strides):
+            ci, ri = get_centers_and_radii(crb, brb, s)
+            ref = base[i].clone()
+            draw_heatmap_batched(ref, ci, ri, 6.0, 0.9, clear=clear)
+            assert torch.equal(fused[i], ref), f"box maps {seed}/{case} stride {s} shape {shapes[i]}"
+        lanes_n, pts = int(rng.integers(1, 5)), int(rng.integers(1, 9))
+        lanes = (torch.rand(b, lanes_n, pts, 2, generator=g) * torch.tensor([sw, sh])).to(DEV)
+        num_points = torch.from_numpy(rng.integers(0, pts + 1, size=(b, lanes_n))).to(DEV)
+        num_lanes = torch.from_numpy(rng.integers(0, lanes_n + 1, size=b)).to(DEV)
+        q, radius = int(rng.choice([1, 17, 64, 128])), int(rng.integers(0, 4))
+        fused = [t.clone() for t in base]
+        draw_polylines_multiscale(fused, lanes, q, radius, strides, 6.0, 0.9, num_points=num_points, num_lanes=num_lanes, clear=clear)
+        for i, s in enumerate(strides):
+            ref = base[i].clone()
+            draw_polylines_batched(ref, lanes, q, radius, s, 6.0, 0.9, num_points=num_points, num_lanes=num_lanes, clear=clear)
+            assert torch.equal(fused[i], ref), f"lane raster {seed}/{case} stride {s} shape {shapes[i]} q {q} r {radius}"
