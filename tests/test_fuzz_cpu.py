@@ -176,3 +176,52 @@ def test_ragged_batch_shape_operations_against_the_list_model(seed):
         pos = torch.arange(t.shape[rbatch.non_uniform_dim]).reshape([-1 if a == rbatch.non_uniform_dim else 1 for a in range(t.dim())])
         valid = pos < rbatch.sample_sizes.reshape(tuple(shape) + (1,) * (t.dim() - nb))
         assert w.shape == t.shape and torch.equal(w, valid.expand(t.shape).to(w.dtype))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _random_tree(rng, depth=0):
+    kinds = ["tensor"] * 5 + ["list", "dict", "tuple", "other", "numpy"] if depth < 3 else ["tensor", "other"]
+    kind = kinds[int(rng.integers(0, len(kinds)))]
+    if kind in ("tensor", "numpy"):
+        dt = [torch.float32, torch.int64, torch.float16, torch.uint8, torch.bool, torch.complex64, torch.float64][int(rng.integers(0, 7))]
+        shape = tuple(int(x) for x in rng.integers(0, 9, size=int(rng.integers(0, 4))))
+        t = (torch.rand(shape) * 50).to(dt) if dt not in (torch.bool, torch.complex64) else \
+            (torch.rand(shape) > 0.5 if dt == torch.bool else torch.complex(torch.rand(shape), torch.rand(shape)))
+        if shape and rng.integers(0, 6) == 0 and t.dim() >= 2:
+            t = t.transpose(0, -1)
+        return t.numpy() if kind == "numpy" and dt != torch.float16 else t
+    if kind == "other":
+        return [None, 3, "text", 2.5][int(rng.integers(0, 4))]
+    items = [_random_tree(rng, depth + 1) for _ in range(int(rng.integers(0, 5)))]
+    return items if kind == "list" else tuple(items) if kind == "tuple" else {f"k{i}": v for i, v in enumerate(items)}
+
+
+def _same_tree(a, b):
+    if isinstance(a, np.ndarray):
+        a = torch.from_numpy(a.copy())          # (np.ascontiguousarray would turn 0-d into 1-d)
+    if isinstance(a, torch.Tensor):
+        return isinstance(b, torch.Tensor) and a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b.cpu())
+    if isinstance(a, (list, tuple)):
+        return type(a) is type(b) and len(a) == len(b) and all(_same_tree(x, y) for x, y in zip(a, b))
+    if isinstance(a, dict):
+        return isinstance(b, dict) and list(a) == list(b) and all(_same_tree(a[k], b[k]) for k in a)
+    return a is b or a == b
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_pack_batch_random_trees_round_trip(seed):
+    """DataLoader hook: pack_batch -> (pickle) -> unpack reproduces nesting, dtypes, shapes and bytes for random trees with empty,
+    non-contiguous, numpy and non-tensor leaves; every packed leaf starts at a multiple of the requested alignment"""
+    import pickle
+
+    from accvlab.multi_tensor_copier import pack_batch
+
+    rng = np.random.default_rng(9990 + seed)
+    for case in range(6):
+        tree = [_random_tree(rng) for _ in range(int(rng.integers(1, 10)))]
+        align = int(rng.choice([1, 6, 16, 64]))
+        pk = pack_batch(tree, min_packed_alignment_bytes=align)
+        assert _same_tree(tree, pk.unpack()), f"seed {seed} case {case}"
+        again = pickle.loads(pickle.dumps(pk))
+        assert _same_tree(tree, again.unpack()), f"seed {seed} case {case}: pickled"
+        assert again.num_tensors == pk.num_tensors and again.num_packed == pk.num_packed

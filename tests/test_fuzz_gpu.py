@@ -151,54 +151,27 @@ def test_h1_flat_api_random_planes_against_the_oracle(seed):
         assert err <= 1e-5, f"seed {seed} case {case}: P {p} {h}x{w} N {n}: max abs err {err}"
 
 
-def _random_tree(rng, depth=0):
-    kinds = ["tensor"] * 5 + ["list", "dict", "tuple", "other"] if depth < 3 else ["tensor", "other"]
-    kind = kinds[int(rng.integers(0, len(kinds)))]
-    if kind == "tensor":
-        dt = [torch.float32, torch.int64, torch.float16, torch.uint8, torch.bool, torch.complex64, torch.float64][int(rng.integers(0, 7))]
-        shape = tuple(int(x) for x in rng.integers(0, 9, size=int(rng.integers(0, 4))))
-        t = (torch.rand(shape) * 50).to(dt) if dt not in (torch.bool, torch.complex64) else \
-            (torch.rand(shape) > 0.5 if dt == torch.bool else torch.complex(torch.rand(shape), torch.rand(shape)))
-        if shape and rng.integers(0, 6) == 0 and t.dim() >= 2:
-            t = t.transpose(0, -1)            # non-contiguous leaf
-        return t
-    if kind == "other":
-        return [None, 3, "text", 2.5][int(rng.integers(0, 4))]
-    n = int(rng.integers(0, 5))
-    items = [_random_tree(rng, depth + 1) for _ in range(n)]
-    if kind == "list":
-        return items
-    if kind == "tuple":
-        return tuple(items)
-    return {f"k{i}": v for i, v in enumerate(items)}
-
-
-def _same(a, b):
-    if isinstance(a, torch.Tensor):
-        return isinstance(b, torch.Tensor) and a.dtype == b.dtype and a.shape == b.shape and torch.equal(a.cpu(), b.cpu())
-    if isinstance(a, (list, tuple)):
-        return type(a) is type(b) and len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
-    if isinstance(a, dict):
-        return isinstance(b, dict) and list(a) == list(b) and all(_same(a[k], b[k]) for k in a)
-    return a is b or a == b
-
-
 @pytest.mark.parametrize("seed", range(6))
 def test_h3_random_trees_round_trip_bit_exact(seed):
-    """start_copy over random nestings / dtypes / empty and non-contiguous leaves, to the GPU and back, both modes, several
-    packing parameters: structure, dtypes, shapes and bytes are preserved"""
-    from accvlab.multi_tensor_copier import start_copy
+    """start_copy over random nestings / dtypes / empty, non-contiguous and numpy leaves, to the GPU and back, both modes, several
+    packing parameters, also through the DataLoader hook (pack_batch): structure, dtypes, shapes and bytes are preserved"""
+    import test_fuzz_cpu as m
+
+    from accvlab.multi_tensor_copier import pack_batch, start_copy
 
     rng = np.random.default_rng(4000 + seed)
     for case in range(5):
-        tree = [_random_tree(rng) for _ in range(int(rng.integers(1, 12)))]
+        tree = [m._random_tree(rng) for _ in range(int(rng.integers(1, 12)))]
         kw = dict(use_background_thread=bool(rng.integers(0, 2)), pack_cpu_tensors=bool(rng.integers(0, 4) > 0),
                   min_packed_alignment_bytes=int(rng.choice([1, 6, 16, 64])), max_packed_chunk_bytes=int(rng.choice([256, 4096, 32 << 20])),
                   use_pinned_staging=bool(rng.integers(0, 4) > 0))
         on_gpu = start_copy(tree, DEV, **kw).get()
-        assert _same(tree, on_gpu), f"seed {seed} case {case} {kw}: host -> GPU"
+        assert m._same_tree(tree, on_gpu), f"seed {seed} case {case} {kw}: host -> GPU"
         back = start_copy(on_gpu, "cpu", **kw).get()
-        assert _same(tree, back), f"seed {seed} case {case} {kw}: GPU -> host"
+        assert m._same_tree(tree, back), f"seed {seed} case {case} {kw}: GPU -> host"
+        via_hook = start_copy(pack_batch(tree, min_packed_alignment_bytes=kw["min_packed_alignment_bytes"]), DEV,
+                              use_background_thread=kw["use_background_thread"]).get()
+        assert m._same_tree(tree, via_hook), f"seed {seed} case {case}: pack_batch -> GPU"
 
 
 def _np(t):
