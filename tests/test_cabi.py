@@ -70,3 +70,23 @@ def test_argument_validation_without_gpu(path):
     assert lib.accv_ragged_gather(None, None, None, None, 0, 4, 4, 4, 16, 0, 0, None, None) == 0
     with pytest.raises(nat.AccvNativeError):
         nat.check(-1, "unit test")
+
+
+@pytest.mark.parametrize("value", [4, 1, 0])
+def test_null_pointer_sweep_is_rejected_or_empty(value):
+    """every int-returning entry point called with NULL for every pointer and `value` for every integer: the call must come
+    back with ACCV_OK (an empty problem / nothing requested), ACCV_EINVAL or ACCV_EWORKSPACE — never crash, and never get as far
+    as a kernel launch (ACCV_ELAUNCH).  accv_memcpy_async is a bare hipMemcpyAsync and reports the runtime's own error."""
+    from accvlab import _amd_native as nat
+
+    lib = nat.ctypes_lib()
+    for name, (res, args) in sorted(nat.SIGNATURES.items()):
+        if res is not ctypes.c_int or not args:
+            continue
+        vals = [None if a in (ctypes.c_void_p, ctypes.c_char_p) else 1.0 if a in (ctypes.c_float, ctypes.c_double) else value
+                for a in args]
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+        status = fn(*vals)
+        allowed = (0, -1, -3, -2) if name == "accv_memcpy_async" else (0, -1, -3)
+        assert status in allowed, f"{name}({value}): status {status}: {lib.accv_last_error()}"
