@@ -411,3 +411,57 @@ def test_multiscale_and_lane_raster_random_against_the_per_scale_operators(seed)
             ref = base[i].clone()
             draw_polylines_batched(ref, lanes, q, radius, s, 6.0, 0.9, num_points=num_points, num_lanes=num_lanes, clear=clear)
             assert torch.equal(fused[i], ref), f"lane raster {seed}/{case} stride {s} shape {shapes[i]} q {q} r {radius}"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_h2_random_gradients_against_torch_autograd(seed):
+    """backward of gather (repeated indices accumulate), inverse, write and mapping against the same expressions written with torch
+    advanced indexing on the GPU (float64: the atomics' summation order is then irrelevant at 1e-10)"""
+    from accvlab.batching_helpers import RaggedBatch, batched_index_mapping, batched_indexing_access, batched_indexing_write, \
+        batched_inverse_indexing_access
+
+    rng = np.random.default_rng(9985 + seed)
+    for case in range(5):
+        b, n_src, n_tgt = int(rng.integers(1, 5)), int(rng.choice([1, 6, 70])), int(rng.choice([3, 40, 90]))
+        n_idx = int(rng.integers(0, min(n_tgt, 30) + 1))
+        inner = tuple(int(x) for x in rng.choice([1, 2, 5], size=int(rng.integers(0, 3))))
+        counts = rng.integers(0, n_idx + 1, size=b)
+        valid = torch.from_numpy(np.arange(n_idx)[None, :] < counts[:, None]).to(DEV)
+        src_idx = torch.from_numpy(rng.integers(0, n_src, size=(b, n_idx))).to(DEV)                       # repeats allowed
+        tgt_idx = torch.from_numpy(np.stack([rng.permutation(n_tgt)[:n_idx] for _ in range(b)]).reshape(b, n_idx)).to(DEV)
+        cnt = torch.from_numpy(counts).to(DEV)
+        rows = torch.arange(b, device=DEV).unsqueeze(1).expand(b, n_idx)
+
+        def leaf(shape):
+            return torch.from_numpy(rng.standard_normal(shape)).to(DEV).requires_grad_(True)
+
+        # gather
+        data, w = leaf((b, n_src) + inner), torch.from_numpy(rng.standard_normal((b, n_idx) + inner)).to(DEV)
+        out = batched_indexing_access(data, RaggedBatch(src_idx, sample_sizes=cnt), 0.0)
+        (out.tensor * w).sum().backward()
+        ref = data.detach().clone().requires_grad_(True)
+        m = valid.reshape(valid.shape + (1,) * len(inner))
+        ((ref[rows, src_idx] * m) * w).sum().backward()
+        assert torch.allclose(data.grad, ref.grad, rtol=1e-10, atol=1e-10), f"gather grad {seed}/{case}"
+        # inverse and write: scatter of `vals` into a fresh / an existing tensor
+        vals, into = leaf((b, n_idx) + inner), leaf((b, n_tgt) + inner)
+        w2 = torch.from_numpy(rng.standard_normal((b, n_tgt) + inner)).to(DEV)
+        tgt_rb = RaggedBatch(tgt_idx, sample_sizes=cnt)
+        o1 = batched_inverse_indexing_access(RaggedBatch(vals, sample_sizes=cnt), tgt_rb, n_tgt, 0.0)
+        o2 = batched_indexing_write(RaggedBatch(vals, sample_sizes=cnt), tgt_rb, into)
+        ((o1 + 2.0 * o2) * w2).sum().backward()
+        v_ref, i_ref = vals.detach().clone().requires_grad_(True), into.detach().clone().requires_grad_(True)
+        r1 = torch.zeros_like(i_ref).index_put((rows[valid], tgt_idx[valid]), v_ref[valid])
+        r2 = i_ref.index_put((rows[valid], tgt_idx[valid]), v_ref[valid])
+        ((r1 + 2.0 * r2) * w2).sum().backward()
+        assert torch.allclose(vals.grad, v_ref.grad, rtol=1e-10, atol=1e-10), f"scatter source grad {seed}/{case}"
+        assert torch.allclose(into.grad, i_ref.grad, rtol=1e-10, atol=1e-10), f"write destination grad {seed}/{case}"
+        # mapping: out[i, tgt] = src[i, src_idx] on a copy of `into2`
+        src, into2 = leaf((b, n_src) + inner), leaf((b, n_tgt) + inner)
+        o3 = batched_index_mapping(src, RaggedBatch(src_idx, sample_sizes=cnt), tgt_rb, into2)
+        (o3 * w2).sum().backward()
+        s_ref, i2_ref = src.detach().clone().requires_grad_(True), into2.detach().clone().requires_grad_(True)
+        r3 = i2_ref.index_put((rows[valid], tgt_idx[valid]), s_ref[rows[valid], src_idx[valid]])
+        (r3 * w2).sum().backward()
+        assert torch.allclose(src.grad, s_ref.grad, rtol=1e-10, atol=1e-10), f"mapping source grad {seed}/{case}"
+        assert torch.allclose(into2.grad, i2_ref.grad, rtol=1e-10, atol=1e-10), f"mapping destination grad {seed}/{case}"
