@@ -465,3 +465,49 @@ def test_h2_random_gradients_against_torch_autograd(seed):
         (r3 * w2).sum().backward()
         assert torch.allclose(src.grad, s_ref.grad, rtol=1e-10, atol=1e-10), f"mapping source grad {seed}/{case}"
         assert torch.allclose(into2.grad, i2_ref.grad, rtol=1e-10, atol=1e-10), f"mapping destination grad {seed}/{case}"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_h2_multi_batch_dims_and_moved_index_dim_equal_the_flat_case(seed):
+    """several batch dimensions and an index dimension that is not the first data dimension: gather, write and boolean
+    compaction must equal the same call on the flattened batch with the indexed dimension moved to the front"""
+    from accvlab.batching_helpers import RaggedBatch, batched_bool_indexing, batched_indexing_access, batched_indexing_write
+
+    rng = np.random.default_rng(9960 + seed)
+    for case in range(5):
+        bshape = tuple(int(x) for x in rng.integers(1, 4, size=int(rng.integers(2, 4))))
+        nb, total = len(bshape), int(np.prod(bshape))
+        n_src, n_idx = int(rng.choice([2, 9, 40])), int(rng.integers(0, 12))
+        extra = int(rng.integers(1, 4))            # one data dimension in front of the indexed one
+        tail = tuple(int(x) for x in rng.integers(1, 4, size=int(rng.integers(0, 2))))
+        data = torch.from_numpy(rng.standard_normal(bshape + (extra, n_src) + tail).astype(np.float32)).to(DEV)
+        idx = torch.from_numpy(rng.integers(0, n_src, size=bshape + (n_idx,))).to(DEV)
+        cnt = torch.from_numpy(rng.integers(0, n_idx + 1, size=bshape)).to(DEV)
+        dim = nb + 1                               # the indexed dimension of `data`
+        got = batched_indexing_access(data, RaggedBatch(idx, sample_sizes=cnt), 2.0, dim_to_index_in=dim)
+        flat_data = data.reshape((total, extra, n_src) + tail).transpose(1, 2).contiguous()
+        flat = batched_indexing_access(flat_data, RaggedBatch(idx.reshape(total, n_idx), sample_sizes=cnt.reshape(total)), 2.0)
+        want = flat.tensor.transpose(1, 2).reshape(bshape + (extra, n_idx) + tail)
+        assert tuple(got.batch_shape) == bshape and got.non_uniform_dim == dim and torch.equal(got.tensor, want), f"gather {seed}/{case}"
+        # write (unique targets)
+        tgt = torch.from_numpy(np.stack([rng.permutation(n_src)[: min(n_idx, n_src)] for _ in range(total)])
+                               .reshape(bshape + (min(n_idx, n_src),))).to(DEV)
+        k = tgt.shape[-1]
+        cnt2 = torch.from_numpy(rng.integers(0, k + 1, size=bshape)).to(DEV)
+        vals = torch.from_numpy(rng.standard_normal(bshape + (extra, k) + tail).astype(np.float32)).to(DEV)
+        got = batched_indexing_write(RaggedBatch(vals, sample_sizes=cnt2, non_uniform_dim=dim), RaggedBatch(tgt, sample_sizes=cnt2), data,
+                                     dim_to_index_in=dim)
+        flat_vals = vals.reshape((total, extra, k) + tail).transpose(1, 2).contiguous()
+        flat = batched_indexing_write(RaggedBatch(flat_vals, sample_sizes=cnt2.reshape(total)),
+                                      RaggedBatch(tgt.reshape(total, k), sample_sizes=cnt2.reshape(total)), flat_data)
+        want = flat.transpose(1, 2).reshape(data.shape)
+        assert torch.equal(got, want), f"write {seed}/{case}"
+        # boolean compaction of a ragged batch with several batch dimensions
+        sizes = torch.from_numpy(rng.integers(0, n_src + 1, size=bshape)).to(DEV)
+        rdata = RaggedBatch(data.transpose(nb, nb + 1).contiguous(), sample_sizes=sizes)            # non-uniform dim right behind the batch
+        mask = torch.from_numpy(rng.random(bshape + (n_src,)) < 0.5).to(DEV)
+        got = batched_bool_indexing(rdata, RaggedBatch(mask, sample_sizes=sizes))
+        flat = batched_bool_indexing(RaggedBatch(rdata.tensor.reshape((total, n_src, extra) + tail), sample_sizes=sizes.reshape(total)),
+                                     RaggedBatch(mask.reshape(total, n_src), sample_sizes=sizes.reshape(total)))
+        assert tuple(got.batch_shape) == bshape and torch.equal(got.sample_sizes.reshape(total), flat.sample_sizes)
+        assert torch.equal(got.tensor.reshape((total,) + tuple(got.tensor.shape[nb:])), flat.tensor), f"bool indexing {seed}/{case}"
