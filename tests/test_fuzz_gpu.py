@@ -511,3 +511,34 @@ def test_h2_multi_batch_dims_and_moved_index_dim_equal_the_flat_case(seed):
                                      RaggedBatch(mask.reshape(total, n_src), sample_sizes=sizes.reshape(total)))
         assert tuple(got.batch_shape) == bshape and torch.equal(got.sample_sizes.reshape(total), flat.sample_sizes)
         assert torch.equal(got.tensor.reshape((total,) + tuple(got.tensor.shape[nb:])), flat.tensor), f"bool indexing {seed}/{case}"
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_h1_extreme_coordinates_and_radii(seed):
+    """centres anywhere in int32 and radii up to 2^30 - 1 (beyond that 2r+1 overflows int32 in the reference as well,
+    cuh:61-62): the 32-bit cull must stay conservative, the exact box must be computed in 64 bits, nothing may be written outside
+    the map, and the values must match the oracle"""
+    from accvlab.draw_heatmap import draw_heatmap_batched
+
+    rng = np.random.default_rng(9940 + seed)
+    big = [0, 1, -1, 2 ** 31 - 1, -2 ** 31, 2 ** 30, -2 ** 30, 2 ** 29 + 3, -2 ** 29 - 3, 65536, -65536]
+    for case in range(6):
+        h, w, b, n = int(rng.choice([5, 40, 130])), int(rng.choice([8, 64, 260])), int(rng.integers(1, 4)), 12
+        cx = np.where(rng.random((b, n)) < 0.5, rng.choice(big, size=(b, n)), rng.integers(-5, w + 5, size=(b, n)))
+        cy = np.where(rng.random((b, n)) < 0.5, rng.choice(big, size=(b, n)), rng.integers(-5, h + 5, size=(b, n)))
+        r = np.where(rng.random((b, n)) < 0.5, rng.choice([2 ** 30 - 1, 2 ** 29, 2 ** 24 + 1, 70000], size=(b, n)), rng.integers(0, 9, size=(b, n)))
+        centers = np.stack([cx, cy], -1).astype(np.int32)
+        radii = r.astype(np.int32)
+        counts = rng.integers(0, n + 1, size=b)
+        clear = bool(rng.integers(0, 2))
+        base = (rng.random((b, h, w), dtype=np.float32) * 0.2).astype(np.float32)
+        want = base.copy()
+        oracle.draw_heatmap_batched(want, centers, radii, counts, clear=clear)
+        buf = torch.full((b * h * w + 512,), -3.0, device=DEV)
+        got = buf[256:256 + b * h * w].view(b, h, w)
+        got.copy_(torch.from_numpy(base))
+        n_t = torch.from_numpy(counts).to(DEV)
+        draw_heatmap_batched(got, rb(torch.from_numpy(centers).to(DEV), n_t), rb(torch.from_numpy(radii).to(DEV), n_t), clear=clear)
+        assert bool((buf[:256] == -3.0).all()) and bool((buf[256 + b * h * w:] == -3.0).all()), f"guard band {seed}/{case}"
+        err = float(np.abs(got.cpu().numpy().astype(np.float64) - want.astype(np.float64)).max())
+        assert err <= 1e-5, f"extreme {seed}/{case}: max abs err {err}"
