@@ -538,7 +538,13 @@ def test_h1_extreme_coordinates_and_radii(seed):
         got = buf[256:256 + b * h * w].view(b, h, w)
         got.copy_(torch.from_numpy(base))
         n_t = torch.from_numpy(counts).to(DEV)
-        draw_heatmap_batched(got, rb(torch.from_numpy(centers).to(DEV), n_t), rb(torch.from_numpy(radii).to(DEV), n_t), clear=clear)
+        from accvlab import _amd_native as nat
+        from accvlab.draw_heatmap import ops
+        ops._FORCED_FLAGS = [0, nat.HM_SMALL_RADII, nat.HM_TILE_ROWS_16, nat.HM_WRITE_THROUGH][(seed + case) % 4]
+        try:
+            draw_heatmap_batched(got, rb(torch.from_numpy(centers).to(DEV), n_t), rb(torch.from_numpy(radii).to(DEV), n_t), clear=clear)
+        finally:
+            ops._FORCED_FLAGS = 0
         assert bool((buf[:256] == -3.0).all()) and bool((buf[256 + b * h * w:] == -3.0).all()), f"guard band {seed}/{case}"
         err = float(np.abs(got.cpu().numpy().astype(np.float64) - want.astype(np.float64)).max())
         assert err <= 1e-5, f"extreme {seed}/{case}: max abs err {err}"
