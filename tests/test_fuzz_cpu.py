@@ -225,3 +225,42 @@ def test_pack_batch_random_trees_round_trip(seed):
         again = pickle.loads(pickle.dumps(pk))
         assert _same_tree(tree, again.unpack()), f"seed {seed} case {case}: pickled"
         assert again.num_tensors == pk.num_tensors and again.num_packed == pk.num_packed
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_lane_sampler_host_path_random_against_the_oracle(seed):
+    """interpolate / lengths on CPU tensors (accv_polyline_sample_host, double accumulation as polyline_cpu.cpp:111-132):
+    float32 and float64, fixed and ragged, zero-length segments, empty polylines, relative mode"""
+    from oracle import lane as oracle_lane
+
+    from accvlab.batching_helpers import RaggedBatch
+    from accvlab.lane_helpers.polyline import interpolate, interpolate_var_size_batch, lengths, lengths_var_size_batch
+
+    rng = np.random.default_rng(9930 + seed)
+    for case in range(6):
+        b, p_max, q_max, dims = int(rng.integers(1, 6)), int(rng.choice([1, 2, 6, 40])), int(rng.choice([1, 5, 70])), int(rng.choice([2, 3]))
+        dt = np.float32 if (seed + case) % 2 else np.float64
+        relative = bool(rng.integers(0, 2))
+        pts = (rng.random((b, p_max, dims)) * 4.0).astype(dt)
+        for i in range(b):
+            for j in range(1, p_max):
+                if rng.random() < 0.15:
+                    pts[i, j] = pts[i, j - 1]
+        dist = ((rng.random((b, q_max)) * 1.4 - 0.2) * (1.0 if relative else 6.0)).astype(dt)
+        tol = 4e-5 if dt == np.float32 else 1e-12
+        got = interpolate(torch.from_numpy(pts), torch.from_numpy(dist), relative=relative).numpy()
+        ln = lengths(torch.from_numpy(pts)).numpy()
+        for i in range(b):
+            assert np.allclose(got[i], oracle_lane.sample(pts[i], dist[i], relative), atol=tol, rtol=0), f"fixed {seed}/{case}/{i}"
+            assert abs(ln[i] - oracle_lane.length(pts[i])) <= tol
+        n_pts, n_q = rng.integers(0, p_max + 1, size=b), rng.integers(0, q_max + 1, size=b)
+        rg = interpolate_var_size_batch(RaggedBatch(torch.from_numpy(pts), sample_sizes=torch.from_numpy(n_pts)),
+                                        RaggedBatch(torch.from_numpy(dist), sample_sizes=torch.from_numpy(n_q)), relative=relative)
+        rl = lengths_var_size_batch(RaggedBatch(torch.from_numpy(pts), sample_sizes=torch.from_numpy(n_pts))).numpy()
+        for i in range(b):
+            want = oracle_lane.sample(pts[i, : n_pts[i]], dist[i, : n_q[i]], relative)
+            have = rg.tensor[i, : n_q[i]].numpy()
+            assert np.array_equal(np.isnan(have), np.isnan(want)) and np.allclose(have, want, atol=tol, rtol=0, equal_nan=True), \
+                f"ragged {seed}/{case}/{i}"
+            wl_ = oracle_lane.length(pts[i, : n_pts[i]])
+            assert (np.isnan(wl_) and np.isnan(rl[i])) or abs(rl[i] - wl_) <= tol
