@@ -548,3 +548,28 @@ def test_h1_extreme_coordinates_and_radii(seed):
         assert bool((buf[:256] == -3.0).all()) and bool((buf[256 + b * h * w:] == -3.0).all()), f"guard band {seed}/{case}"
         err = float(np.abs(got.cpu().numpy().astype(np.float64) - want.astype(np.float64)).max())
         assert err <= 1e-5, f"extreme {seed}/{case}: max abs err {err}"
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_target_front_end_random_against_float32_numpy(seed):
+    """get_centers_and_radii: c = int(c / stride), r = max(1, ceil(min edge distance / stride)) in IEEE float32
+    (packages/draw_heatmap/tests/_test_helpers.py:20-28) — bit-exact against numpy float32 for random boxes incl. degenerate and
+    inverted ones, centres outside their box, large coordinates, odd strides"""
+    from accvlab.draw_heatmap import get_centers_and_radii
+
+    rng = np.random.default_rng(9920 + seed)
+    for case in range(6):
+        shape = tuple(int(x) for x in rng.integers(1, 40, size=int(rng.integers(1, 3))))
+        scale = float(rng.choice([1.0, 100.0, 5000.0, 1e6]))
+        c = ((rng.random(shape + (2,)) - 0.2) * scale).astype(np.float32)
+        half = ((rng.random(shape + (4,)) - 0.1) * scale * 0.3).astype(np.float32)
+        boxes = np.concatenate([c - half[..., :2], c + half[..., 2:]], -1).astype(np.float32)
+        stride = np.float32(rng.choice([1.0, 2.0, 3.0, 4.0, 7.5, 16.0, 0.37]))
+        ci, ri = get_centers_and_radii(torch.from_numpy(c).to(DEV), torch.from_numpy(boxes).to(DEV), float(stride))
+        m = np.minimum(np.minimum(c[..., 0] - boxes[..., 0], c[..., 1] - boxes[..., 1]),
+                       np.minimum(boxes[..., 2] - c[..., 0], boxes[..., 3] - c[..., 1])).astype(np.float32)
+        want_r = np.maximum(1, np.ceil((m / stride).astype(np.float32))).astype(np.int64)
+        want_c = np.trunc((c / stride).astype(np.float32)).astype(np.int64)
+        assert ci.dtype == torch.int32 and ri.dtype == torch.int32
+        assert np.array_equal(ci.cpu().numpy().astype(np.int64), want_c), f"centres {seed}/{case}"
+        assert np.array_equal(ri.cpu().numpy().astype(np.int64), want_r), f"radii {seed}/{case}"
