@@ -1091,10 +1091,10 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
         return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: negative count");
     if (max_num_targets > (1 << 30))
         return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: more than 2^30 objects per sample");
-    // (an empty [B, 0] label tensor has no storage: with no object slots the pointer is not looked at)
+    if (batch == 0 || height == 0 || width == 0) return ACCV_OK;
+    // (an empty [B, 0] or [0, N] label tensor has no storage: without object slots the pointer is not looked at)
     if (max_num_targets > 0 && (num_classes > 0) != (labels != nullptr))
         return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: labels and num_classes must be given together");
-    if (batch == 0 || height == 0 || width == 0) return ACCV_OK;
     if (!heatmap) return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: heatmap pointer is null");
     if (!counts) return accv::fail(ACCV_EINVAL, "draw_heatmap_batched: counts pointer is null");
     if (max_num_targets > 0 && (!centers || !radii))

@@ -573,3 +573,55 @@ def test_target_front_end_random_against_float32_numpy(seed):
         assert ci.dtype == torch.int32 and ri.dtype == torch.int32
         assert np.array_equal(ci.cpu().numpy().astype(np.int64), want_c), f"centres {seed}/{case}"
         assert np.array_equal(ri.cpu().numpy().astype(np.int64), want_r), f"radii {seed}/{case}"
+
+
+def test_degenerate_extents_do_not_trip_any_operator():
+    """zero batches, zero-sized maps, zero objects / indices / points: every public operator returns (correctly shaped) results
+    instead of tripping over an empty tensor's null data pointer or an ambiguous reshape"""
+    from accvlab.batching_helpers import (RaggedBatch, batched_bool_indexing, batched_index_mapping, batched_indexing_access,
+                                          batched_indexing_write, batched_inverse_indexing_access, combine_data, get_compact_lists,
+                                          get_indices_from_mask, get_mask_from_indices, matched_pair_loss_sum)
+    from accvlab.draw_heatmap import (draw_heatmap, draw_heatmap_batched, draw_heatmap_multiscale, draw_polylines_batched,
+                                      draw_polylines_multiscale, get_centers_and_radii)
+    from accvlab.lane_helpers.polyline import interpolate, lengths
+    from accvlab.multi_tensor_copier import start_copy
+
+    i32, i64, f32 = torch.int32, torch.int64, torch.float32
+
+    def z(*shape, dtype=f32):
+        return torch.zeros(shape, dtype=dtype, device=DEV)
+
+    for b, h, w, n in ((0, 8, 8, 3), (2, 0, 8, 3), (2, 8, 0, 3), (2, 8, 8, 0), (0, 0, 0, 0)):
+        for clear in (True, False):
+            draw_heatmap_batched(z(b, h, w), rb(z(b, n, 2, dtype=i32), z(b, dtype=i64)), rb(z(b, n, dtype=i32), z(b, dtype=i64)), clear=clear)
+            draw_heatmap_batched(z(b, 3, h, w), rb(z(b, n, 2, dtype=i32), z(b, dtype=i64)), rb(z(b, n, dtype=i32), z(b, dtype=i64)),
+                                 labels=rb(z(b, n, dtype=i32), z(b, dtype=i64)), clear=clear)
+            draw_heatmap(z(b, h, w), z(n, 2, dtype=i32), z(n, dtype=i32), z(n, dtype=i32), clear=clear)
+            crb = RaggedBatch(z(b, n, 2), sample_sizes=z(b, dtype=i64))
+            draw_heatmap_multiscale([z(b, h, w), z(b, h // 2, w // 2)], crb, z(b, n, 4), (1.0, 2.0), clear=clear)
+            draw_polylines_batched(z(b, h, w), z(b, 2, n, 2), 4, 1, 1.0, clear=clear)
+            draw_polylines_multiscale([z(b, h, w)], z(b, 0, 3, 2), 4, 1, (1.0,), clear=clear)
+    c, r = get_centers_and_radii(z(0, 2), z(0, 4), 4.0)
+    assert c.shape == (0, 2) and r.shape == (0,)
+    assert interpolate(z(0, 5, 2), z(0, 3)).shape == (0, 3, 2) and lengths(z(0, 5, 2)).shape == (0,)
+    assert interpolate(z(2, 5, 2), z(2, 0)).shape == (2, 0, 2)
+    assert bool(torch.isnan(interpolate(z(2, 0, 2), z(2, 3))).all())
+    for b, n_src, n_idx in ((0, 4, 3), (2, 4, 0), (2, 0, 0), (0, 0, 0)):
+        idx = RaggedBatch(z(b, n_idx, dtype=i64), sample_sizes=z(b, dtype=i64))
+        out = batched_indexing_access(z(b, n_src, 3), idx, 1.0)
+        assert tuple(out.tensor.shape) == (b, n_idx, 3)
+        assert tuple(batched_inverse_indexing_access(RaggedBatch(z(b, n_idx, 3), sample_sizes=z(b, dtype=i64)), idx, 5, 1.0).shape) == (b, 5, 3)
+        assert tuple(batched_indexing_write(RaggedBatch(z(b, n_idx, 3), sample_sizes=z(b, dtype=i64)), idx, z(b, 5, 3)).shape) == (b, 5, 3)
+        assert tuple(batched_index_mapping(z(b, n_src, 3), idx, idx, z(b, 5, 3)).shape) == (b, 5, 3)
+        assert tuple(get_mask_from_indices(5, idx).shape) == (b, 5)
+        assert tuple(matched_pair_loss_sum(z(b, n_src, 3), z(b, n_src, 3), idx, idx).shape) == (b,)
+        mask = torch.zeros((b, n_src), dtype=torch.bool, device=DEV)
+        comp = batched_bool_indexing(z(b, n_src, 3), mask)
+        assert tuple(comp.tensor.shape) == (b, 0, 3) and tuple(get_indices_from_mask(mask).tensor.shape) == (b, 0)
+        assert tuple(get_compact_lists(mask, [z(b, n_src)])[0].tensor.shape) == (b, 0)
+    empty = combine_data([torch.zeros(0, 4), torch.zeros(0, 4)], device=DEV)
+    assert tuple(empty.tensor.shape) == (2, 0, 4) and [tuple(t.shape) for t in empty.split()] == [(0, 4), (0, 4)]
+    for tree in ([], {}, (), [torch.zeros(0)], {"a": [torch.zeros(0, 3), ()], "b": None}):
+        got = start_copy(tree, DEV).get()
+        assert type(got) is type(tree) and len(got) == len(tree)
+        assert start_copy(got, "cpu", use_background_thread=False).get() is not None
