@@ -625,3 +625,81 @@ def test_degenerate_extents_do_not_trip_any_operator():
         got = start_copy(tree, DEV).get()
         assert type(got) is type(tree) and len(got) == len(tree)
         assert start_copy(got, "cpu", use_background_thread=False).get() is not None
+
+
+@pytest.mark.parametrize("background", [True, False])
+def test_copier_many_outstanding_handles_in_random_order(background):
+    """40 copies in flight at once (pinned arena blocks, side-stream DMAs and — in background mode — tickets of the native
+    orchestrator all outstanding), results fetched in random order, some handles dropped without get(): every result is exact and
+    later copies still work"""
+    import gc
+
+    import test_fuzz_cpu as m
+
+    from accvlab.multi_tensor_copier import start_copy
+
+    rng = np.random.default_rng(777 + int(background))
+    trees = [[m._random_tree(rng) for _ in range(int(rng.integers(1, 8)))] + [torch.randn(int(rng.integers(1, 5000)))] for _ in range(40)]
+    handles = [start_copy(t, DEV, use_background_thread=background, max_packed_chunk_bytes=int(rng.choice([512, 8192, 32 << 20])))
+               for t in trees]
+    order = rng.permutation(len(handles))
+    dropped = set(int(i) for i in order[:6])
+    for i in order:
+        if int(i) in dropped:
+            handles[int(i)] = None            # the destructor must wait for the transfer and release the staging
+            continue
+        h = handles[int(i)]
+        while not h.ready():
+            pass
+        assert m._same_tree(trees[int(i)], h.get()), f"job {i}"
+    gc.collect()
+    again = start_copy(trees[0], DEV, use_background_thread=background).get()
+    assert m._same_tree(trees[0], again)
+    # and back to the host with everything in flight at once
+    gpu_trees = [start_copy(t, DEV).get() for t in trees[:15]]
+    back = [start_copy(g, "cpu", use_background_thread=background) for g in gpu_trees]
+    for t, h in zip(trees[:15], back):
+        assert m._same_tree(t, h.get())
+
+
+def test_operators_on_two_streams_and_two_threads():
+    """the library keeps no per-call global state: draws and ragged gathers issued from two python threads, each on its own
+    stream, give the single-threaded results"""
+    import threading
+
+    import bench_workloads as wl
+    from accvlab.batching_helpers import RaggedBatch, batched_indexing_access, combine_data
+    from accvlab.draw_heatmap import draw_heatmap_batched
+
+    cl, rl = wl.heatmap_objects(6, 270, 480, 1, 40, "A", seed=5)
+    c = combine_data(cl, device=DEV)
+    r = combine_data(rl, device=DEV, other_with_same_sample_sizes=c)
+    want = torch.empty(6, 270, 480, device=DEV)
+    draw_heatmap_batched(want, c, r, clear=True)
+    data = torch.randn(8, 300, 16, device=DEV)
+    idx = RaggedBatch(torch.randint(0, 300, (8, 50), device=DEV), sample_sizes=torch.randint(0, 51, (8,), device=DEV))
+    want_g = batched_indexing_access(data, idx, 0.5).tensor.clone()
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(40):
+                    hm = torch.empty(6, 270, 480, device=DEV)
+                    draw_heatmap_batched(hm, c, r, clear=True)
+                    g = batched_indexing_access(data, idx, 0.5).tensor
+                    if not (torch.equal(hm, want) and torch.equal(g, want_g)):
+                        errors.append(f"thread {k}: mismatch")
+                        return
+            s.synchronize()
+        except Exception as exc:      # noqa: BLE001
+            errors.append(f"thread {k}: {exc!r}")
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
