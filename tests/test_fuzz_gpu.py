@@ -703,3 +703,64 @@ def test_operators_on_two_streams_and_two_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_whole_target_prep_step_replays_from_one_hip_graph():
+    """box maps + lane raster (all strides) + ragged gather / write / mask + fused matched loss + pad fill captured into ONE
+    hipGraph and replayed after the inputs were overwritten in place: every output equals the eager result for the new inputs
+    (nothing in the hot path synchronises, allocates outside the stream-ordered allocator or reads host state at launch time)"""
+    from accvlab.batching_helpers import (RaggedBatch, batched_index_mapping, batched_indexing_access, batched_indexing_write,
+                                          get_mask_from_indices, matched_pair_loss_sum)
+    from accvlab.draw_heatmap import draw_heatmap_multiscale, draw_polylines_multiscale
+
+    g = torch.Generator().manual_seed(3)
+    b, n, sw, sh = 4, 16, 640, 384
+    strides = (4.0, 8.0, 16.0)
+
+    def inputs(seed):
+        gg = torch.Generator().manual_seed(seed)
+        c = torch.rand(b, n, 2, generator=gg) * torch.tensor([sw, sh])
+        half = torch.rand(b, n, 4, generator=gg) * 60
+        boxes = torch.cat([c - half[..., :2], c + half[..., 2:]], -1)
+        cnt = torch.randint(0, n + 1, (b,), generator=gg)
+        lanes = torch.rand(b, 3, 10, 2, generator=gg) * torch.tensor([sw, sh])
+        data = torch.randn(b, 50, 8, generator=gg)
+        idx = torch.randint(0, 50, (b, 12), generator=gg)
+        tgt = torch.stack([torch.randperm(50, generator=gg)[:12] for _ in range(b)])
+        icnt = torch.randint(0, 13, (b,), generator=gg)
+        return [t.to(DEV) for t in (c, boxes, cnt, lanes, data, idx, tgt, icnt)]
+
+    static = inputs(1)
+
+    def step(c, boxes, cnt, lanes, data, idx, tgt, icnt):
+        box_maps = [torch.empty(b, int(sh / s), int(sw / s), device=DEV) for s in strides]
+        lane_maps = [torch.empty_like(m_) for m_ in box_maps]
+        draw_heatmap_multiscale(box_maps, RaggedBatch(c, sample_sizes=cnt), boxes, strides, clear=True)
+        draw_polylines_multiscale(lane_maps, lanes, 64, 2, strides, clear=True)
+        irb, trb = RaggedBatch(idx, sample_sizes=icnt), RaggedBatch(tgt, sample_sizes=icnt)
+        gathered = batched_indexing_access(data, irb, 0.0)
+        written = batched_indexing_write(gathered, trb, data)
+        mapped = batched_index_mapping(data, irb, trb, data)
+        mask = get_mask_from_indices(50, trb)
+        loss = matched_pair_loss_sum(data, written, irb, trb, kind="smooth_l1")
+        padded = gathered.with_padded_set_to(-1.0).tensor
+        return box_maps + lane_maps + [gathered.tensor, written, mapped, mask, loss, padded]
+
+    for _ in range(2):                                   # warm-up on a side stream, as torch's capture recipe asks
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step(*static)
+        torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = step(*static)
+    for seed in (2, 3):
+        fresh = inputs(seed)
+        for dst, src in zip(static, fresh):
+            dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = step(*[t.clone() for t in fresh])
+        for k, (a, w) in enumerate(zip(outs, want)):
+            assert torch.equal(a, w), f"replay with inputs {seed}: output {k} differs from the eager result"
