@@ -11,6 +11,11 @@ Shapes: ground truth ragged per frame — boxes ``[B, G*, 4]`` (x0,y0,x1,y1), la
 """
 from __future__ import annotations
 
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "accv-lab_amd"))   # run from a checkout
+
 import torch
 from scipy.optimize import linear_sum_assignment
 

@@ -10,6 +10,11 @@ Used by tests/test_pipeline_gpu.py, which checks every stage against the CPU ora
 """
 from __future__ import annotations
 
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "accv-lab_amd"))   # run from a checkout
+
 import time
 from typing import Dict, List
 
