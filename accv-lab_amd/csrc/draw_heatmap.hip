@@ -1125,6 +1125,7 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
                                      float k_scale, unsigned flags, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    (void)take_launch_events();   // a pending accv_draw_heatmap_time_next_launch pair is dropped, not kept for a later call
     if (num_scales < 1 || num_scales > kMaxScales)
         return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: 1..%d scales supported, got %d", kMaxScales, num_scales);
     if (!heatmaps || !heights || !widths || !strides) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: null array");
@@ -1208,6 +1209,7 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
                                     void* workspace, size_t workspace_bytes, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    (void)take_launch_events();   // a pending accv_draw_heatmap_time_next_launch pair is dropped, not kept for a later call
     if (num_scales < 1 || num_scales > kMaxScales)
         return accv::fail(ACCV_EINVAL, "draw_points_multiscale: 1..%d scales supported, got %d", kMaxScales, num_scales);
     if (!heatmaps || !heights || !widths || !strides) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: null array");

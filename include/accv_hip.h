@@ -65,8 +65,8 @@ const char* accv_draw_heatmap_last_dispatch(void);
  * accv_draw_heatmap_batched_f32 call made by the calling thread records `start_event` when it begins to execute and
  * `stop_event` when it has finished (hipExtLaunchKernel), i.e. the kernel's own duration, without the dispatch gap that
  * separates back-to-back launches on a stream.  Both are hipEvent_t with timing enabled (either may be NULL).  One-shot:
- * that call consumes the pair whether or not it launches (a call that returns early leaves the events unrecorded);
- * (NULL, NULL) cancels.  bench.py derives roofline.kernel_ms from it; kernel and launch parameters are unchanged. */
+ * that call consumes the pair whether or not it launches (a call that returns early leaves the events unrecorded), and a
+ * multi-scale draw call in between drops it; (NULL, NULL) cancels.  bench.py derives roofline.kernel_ms from it; kernel and launch parameters are unchanged. */
 int accv_draw_heatmap_time_next_launch(void* start_event, void* stop_event);
 
 /* Replaces draw_heatmap_launcher / draw_heatmap_cuda  (packages/draw_heatmap/accvlab/draw_heatmap/csrc/
