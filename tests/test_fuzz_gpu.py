@@ -764,3 +764,48 @@ def test_whole_target_prep_step_replays_from_one_hip_graph():
         want = step(*[t.clone() for t in fresh])
         for k, (a, w) in enumerate(zip(outs, want)):
             assert torch.equal(a, w), f"replay with inputs {seed}: output {k} differs from the eager result"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_combine_data_to_the_gpu_random(seed):
+    """combine_data with a GPU target: CPU samples (pinned padded pack or flat + pack kernel, depending on the size), GPU samples,
+    nested lists with and without flattening, shared sample sizes, gradients — equal to the CPU result of the same call"""
+    from accvlab.batching_helpers import combine_data
+
+    rng = np.random.default_rng(9910 + seed)
+    dts = [torch.float32, torch.float64, torch.int64, torch.int32, torch.float16, torch.uint8, torch.bool]
+    for case in range(6):
+        outer, inner_b = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        feat = tuple(int(x) for x in rng.integers(1, 6, size=int(rng.integers(0, 3))))
+        dt = dts[(seed + case) % len(dts)]
+        big = bool(rng.integers(0, 4) == 0)                      # > 1 MB: the flat + pack-kernel route
+        max_n = 3000 if big else 6
+
+        def sample():
+            n = int(rng.integers(0, max_n))
+            a = rng.random((n,) + feat) * 60
+            return torch.from_numpy(a > 30) if dt == torch.bool else torch.from_numpy(a).to(dt)
+
+        nested = [[sample() for _ in range(inner_b)] for _ in range(outer)]
+        for flatten in (True, False):
+            if not flatten and all(t.shape[0] == 0 for row in nested for t in row):
+                continue      # the reference's own corner: float32 [*batch, 0] on the CPU unless `device` is given (:527-535)
+            want = combine_data(nested, flatten_batch_dims=flatten)
+            from_cpu = combine_data(nested, device=DEV, flatten_batch_dims=flatten)
+            from_gpu = combine_data([[t.to(DEV) for t in row] for row in nested], flatten_batch_dims=flatten)
+            for got in (from_cpu, from_gpu):
+                assert got.tensor.is_cuda and got.tensor.dtype == dt and tuple(got.batch_shape) == tuple(want.batch_shape)
+                assert torch.equal(got.sample_sizes.cpu(), want.sample_sizes) and torch.equal(got.tensor.cpu(), want.tensor)
+                assert torch.equal(got.mask.cpu(), want.mask)
+            shared = combine_data(nested, device=DEV, other_with_same_sample_sizes=from_cpu, flatten_batch_dims=flatten)
+            assert shared.sample_sizes is from_cpu.sample_sizes and torch.equal(shared.tensor, from_cpu.tensor)
+        if dt in (torch.float32, torch.float64) and any(t.shape[0] for row in nested for t in row):
+            leaves = [t.clone().to(DEV).requires_grad_(True) for row in nested for t in row]
+            rb_ = combine_data(leaves)
+            w = torch.rand(rb_.tensor.shape, device=DEV, dtype=dt)
+            (rb_.tensor * w).sum().backward()
+            for i, leaf in enumerate(leaves):
+                if leaf.shape[0] == 0:      # the reference skips empty samples (`if size_elem > 0`, :421-423): no gradient at all
+                    assert leaf.grad is None
+                else:
+                    assert torch.equal(leaf.grad, w[i, : leaf.shape[0]]), f"grad {seed}/{case}/{i}"
