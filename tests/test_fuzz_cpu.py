@@ -264,3 +264,42 @@ def test_lane_sampler_host_path_random_against_the_oracle(seed):
                 f"ragged {seed}/{case}/{i}"
             wl_ = oracle_lane.length(pts[i, : n_pts[i]])
             assert (np.isnan(wl_) and np.isnan(rl[i])) or abs(rl[i] - wl_) <= tol
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_masked_reductions_against_the_list_model(seed):
+    """sum_over_targets / average_over_targets (empty samples: 0 or NaN) / apply_mask_to_tensor / squeeze_except_batch_and_sample
+    over random batch shapes and positions of the non-uniform dimension, against per-sample sums of the valid entries"""
+    from accvlab.batching_helpers import apply_mask_to_tensor, average_over_targets, squeeze_except_batch_and_sample, sum_over_targets
+
+    rng = np.random.default_rng(9700 + seed)
+    for case in range(8):
+        rbatch, nb, nu_pos = _random_ragged(rng)
+        leaves = _model(rbatch)
+        shape = tuple(rbatch.batch_shape)
+        data_shape = list(rbatch.tensor.shape[nb:])
+        del data_shape[nu_pos]
+        want_sum = torch.stack([l.sum(dim=nu_pos) for l in leaves]).reshape(shape + tuple(data_shape))
+        assert torch.allclose(sum_over_targets(rbatch), want_sum, rtol=1e-12, atol=1e-12), f"sum {seed}/{case}"
+        sizes = rbatch.sample_sizes.reshape(shape + (1,) * len(data_shape)).to(torch.float64)
+        # the average first SWAPS the non-uniform dimension with the first data dimension (as the reference does,
+        # batched_processing_py.py:35-37): its data dimensions come out in that swapped order
+        swapped = torch.stack([l.transpose(0, nu_pos).sum(dim=0) for l in leaves])
+        want_avg_sum = swapped.reshape(shape + tuple(swapped.shape[1:]))
+        avg = average_over_targets(rbatch)
+        assert torch.allclose(avg, torch.where(sizes > 0, want_avg_sum / sizes.clamp(min=1), torch.zeros_like(want_avg_sum)),
+                              rtol=1e-12, atol=1e-12), f"average {seed}/{case}"
+        avg_nan = average_over_targets(rbatch, nans_to_zero=False)
+        assert torch.equal(torch.isnan(avg_nan), (sizes == 0).expand(avg_nan.shape))
+        # a mask over the leading dimensions, broadcast over the rest
+        t = rbatch.tensor
+        lead = int(rng.integers(1, t.dim() + 1))
+        mask = torch.from_numpy(rng.random(tuple(t.shape[:lead])) < 0.5)
+        masked = apply_mask_to_tensor(t, mask, -2.0)
+        m = mask.reshape(tuple(mask.shape) + (1,) * (t.dim() - lead)).expand(t.shape)
+        assert torch.equal(masked, torch.where(m, t, torch.full_like(t, -2.0)))
+        # squeeze: data dimensions of extent 1 go, batch and non-uniform dimensions stay
+        sq = squeeze_except_batch_and_sample(rbatch)
+        keep = [i for i in range(t.dim()) if i < nb or i == rbatch.non_uniform_dim or t.shape[i] != 1]
+        assert tuple(sq.tensor.shape) == tuple(t.shape[i] for i in keep) and sq.non_uniform_dim == keep.index(rbatch.non_uniform_dim)
+        assert torch.equal(sq.tensor, t.reshape(sq.tensor.shape)) and torch.equal(sq.sample_sizes, rbatch.sample_sizes)
