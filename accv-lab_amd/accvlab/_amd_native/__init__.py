@@ -108,16 +108,16 @@ _BLOCKING = {"accv_mtc_async_wait", "accv_mtc_stage_h2d", "accv_mtc_pack_host", 
 def _fast_entry(fn, res, args):
     """A callable with the C argument order that goes through the trampoline, or None when the signature is not
     eligible (non-int result, string arguments, a float count other than 0 or 2)."""
-    if _fastcall is None or res is not _i or len(args) > 18:
+    if _fastcall is None or res is not _i or len(args) > 22:
         return None
     floats = [k for k, a in enumerate(args) if a is _f]
     if any(a is not _f and a not in _INT_CLASS for a in args):
         return None
     addr = ctypes.cast(fn, ctypes.c_void_p).value
-    if not floats and len(args) <= 16:
+    if not floats and len(args) <= 20:
         import functools
         return functools.partial(_fastcall.call_ints, addr)
-    if len(floats) == 2 and floats[1] == floats[0] + 1 and len(args) - 2 <= 16:
+    if len(floats) == 2 and floats[1] == floats[0] + 1 and len(args) - 2 <= 20:
         f0, call = floats[0], _fastcall.call_f2
         return lambda *a: call(addr, a[f0], a[f0 + 1], *a[:f0], *a[f0 + 2:])
     return None

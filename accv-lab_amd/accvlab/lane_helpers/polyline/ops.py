@@ -6,6 +6,8 @@ implementation that accumulates in float64 (the reference's CPU path accumulates
 """
 from __future__ import annotations
 
+import functools
+
 import torch
 
 from ... import _amd_native as _nat
@@ -55,6 +57,12 @@ def _check_size_values(checks):
             raise RuntimeError(f"{name} values must be in [0, {limit}]")
 
 
+@functools.lru_cache(maxsize=256)
+def _scratch_bytes(batch: int, max_points: int, code: int) -> int:
+    """accv_polyline_scratch_bytes, remembered per shape (a size_t result goes through ctypes: ~3 us per call)"""
+    return int(_nat.lib().accv_polyline_scratch_bytes(batch, max_points, code))
+
+
 def _gpu(points, distances, p_sizes, d_sizes, relative, want_points, want_lengths, group_boxes_ptr=0):
     """``group_boxes_ptr``: device pointer for the bounding boxes of every 64 consecutive samples (f32, 2-D points only;
     accv_polyline_sample_boxes) or 0."""
@@ -81,7 +89,7 @@ def _gpu(points, distances, p_sizes, d_sizes, relative, want_points, want_length
         if d_sizes is not None:
             d_sizes = d_sizes.to(want).contiguous()
     with _nat.device_guard(points.device):
-        sb = lib.accv_polyline_scratch_bytes(b, pmax, code)
+        sb = _scratch_bytes(b, pmax, code)
         scratch = torch.empty(sb, dtype=torch.uint8, device=points.device) if sb else None
         _nat.check(lib.accv_polyline_sample_boxes(
             points.data_ptr(), distances.data_ptr() if distances is not None else None,

@@ -15,6 +15,8 @@
 // scratch row instead (same code path, pointer swap).
 #include <hip/hip_runtime.h>
 
+#include <climits>
+
 #include <cmath>
 #include <limits>
 #include <thread>
@@ -89,6 +91,7 @@ struct PolyParams {
     long long batch;
     int P, Q, D;
     int counts_i64, relative, use_scratch;
+    int q_chunk;            // queries per workgroup: blockIdx.y walks the chunks of one polyline (multiple of kThreads)
 };
 
 __device__ __forceinline__ long long load_count(const void* p, long long i, int is64)
@@ -114,14 +117,20 @@ __global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
     T* out = p.out_points ? static_cast<T*>(p.out_points) + (size_t)b * p.Q * p.D : nullptr;
     const Acc nan = std::numeric_limits<Acc>::quiet_NaN();
 
+    // this workgroup's share of the queries: many queries of few polylines are spread over several workgroups (each repeats
+    // the prefix scan, which is cheap next to thousands of binary searches by one workgroup while most of the chip idles)
+    const int q_begin = (int)blockIdx.y * p.q_chunk;
+    const int q_stop = min(q, q_begin + p.q_chunk), q_cap = min(p.Q, q_begin + p.q_chunk);
+    const bool first_chunk = blockIdx.y == 0;
+
     if (n == 0) {  // undefined polyline: NaN everywhere (polyline_kernels.cuh:216-225)
         if (out)
-            for (int i = t; i < q * p.D; i += kThreads) S::store(out + i, nan);
-        if (p.out_lengths && t == 0) S::store(static_cast<T*>(p.out_lengths) + b, nan);
+            for (int i = q_begin * p.D + t; i < q_stop * p.D; i += kThreads) S::store(out + i, nan);
+        if (p.out_lengths && t == 0 && first_chunk) S::store(static_cast<T*>(p.out_lengths) + b, nan);
         if (p.out_boxes) {
             const int groups = (p.Q + 63) / 64;
             const float inf = __builtin_inff();
-            for (int g = t; g < groups; g += kThreads)
+            for (int g = (q_begin >> 6) + t; g < min(groups, (q_cap + 63) >> 6); g += kThreads)
                 reinterpret_cast<float4*>(p.out_boxes)[b * groups + g] = make_float4(inf, inf, -inf, -inf);
         }
         return;
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
     __syncthreads();
 
     const Acc total = accum[n - 1];
-    if (p.out_lengths && t == 0) S::store(static_cast<T*>(p.out_lengths) + b, total);
+    if (p.out_lengths && t == 0 && first_chunk) S::store(static_cast<T*>(p.out_lengths) + b, total);
     if (!out) return;
 
     // ---- queries
@@ -178,11 +187,11 @@ __global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
     const Acc eps = std::numeric_limits<Acc>::epsilon();
     // (whole waves walk the loop together: when group boxes are wanted, the 64 lanes of a wave hold 64 consecutive samples
     // and reduce their bounding box with shuffles)
-    const int q_span = p.out_boxes ? ((p.Q + kThreads - 1) / kThreads) * kThreads : q;
+    const int q_span = p.out_boxes ? q_begin + ((q_cap - q_begin + kThreads - 1) / kThreads) * kThreads : q_stop;
     const int groups = (p.Q + 63) / 64;
-    for (int i = t; i < q_span; i += kThreads) {
+    for (int i = q_begin + t; i < q_span; i += kThreads) {
         float bx = __builtin_nanf(""), by = bx;  // sample coordinates for the group box (D == 2, f32 instantiation)
-        if (i < q) {
+        if (i < q_stop) {
             Acc d = S::load(dist + i);
             if (p.relative) d *= total;
             T* res = out + (size_t)i * p.D;
@@ -295,7 +304,19 @@ int accv_polyline_sample_boxes(const void* points, const void* distances, const 
         lds = 16;
     }
     if (!p.out_points && !p.out_lengths) return ACCV_OK;
-    const dim3 grid((unsigned)batch), block(kThreads);
+    // queries per workgroup: everything, unless few polylines carry thousands of queries each — then the queries of a polyline
+    // are cut into chunks (multiples of the workgroup size, so that groups of 64 samples never straddle a chunk), as many as
+    // keep the launch at <= ~4096 workgroups (batch 64, 5000 x 5000: 50 us with one workgroup per polyline; profiles/r02_bench_published.jsonl)
+    long long chunks = 1;
+    // (every chunk repeats the scan over max_points, so a chunk should hold at least ~max_points / 4 queries)
+    const long long min_chunk = std::max<long long>(kThreads, ((max_points / 4 + kThreads - 1) / kThreads) * kThreads);
+    if (p.out_points && !p.use_scratch && max_distances >= 2 * min_chunk && batch < 2048)
+        chunks = std::max<long long>(1, std::min<long long>((max_distances + min_chunk - 1) / min_chunk, 4096 / batch));
+    const long long per_chunk = (max_distances + chunks - 1) / chunks;
+    p.q_chunk = (int)std::min<long long>(((per_chunk + kThreads - 1) / kThreads) * kThreads, (long long)INT_MAX - kThreads);
+    if (p.q_chunk < kThreads) p.q_chunk = kThreads;
+    chunks = std::max<long long>(1, ((long long)max_distances + p.q_chunk - 1) / p.q_chunk);
+    const dim3 grid((unsigned)batch, (unsigned)chunks), block(kThreads);
     switch (dtype) {
         case kPF32: hipLaunchKernelGGL((polyline_kernel<kPF32>), grid, block, lds, stream, p); break;
         case kPF64: hipLaunchKernelGGL((polyline_kernel<kPF64>), grid, block, lds, stream, p); break;

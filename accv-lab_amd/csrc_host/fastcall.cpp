@@ -12,7 +12,7 @@
 // objects with the buffer protocol such as ctypes / numpy arrays (-> address of their memory).
 // x86-64 System V only (the ABI of the ROCm image): integer-class arguments travel in rdi..r9 and then in 8-byte stack
 // slots in declaration order whatever their C width, float arguments in xmm0.. independently of their position, and the
-// caller pops the stack — so one 16-slot signature serves every entry point of the header with up to 16 integer-class
+// caller pops the stack — so one 20-slot signature serves every entry point of the header with up to 20 integer-class
 // and 2 float parameters (extra slots are ignored by the callee).  Plumbing only: no device code, no HIP calls.
 #include <torch/extension.h>
 
@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr Py_ssize_t kMaxInts = 16;
+constexpr Py_ssize_t kMaxInts = 20;
 
 bool convert(PyObject* const* args, Py_ssize_t n, uint64_t (&a)[kMaxInts])
 {
@@ -61,14 +61,15 @@ bool convert(PyObject* const* args, Py_ssize_t n, uint64_t (&a)[kMaxInts])
 }
 
 using IntFn = int (*)(uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t,
-                      uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t);
+                      uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t);
 using F2Fn = int (*)(float, float, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t,
-                     uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t);
+                     uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t,
+                     uint64_t);
 
 PyObject* call_ints(PyObject*, PyObject* const* args, Py_ssize_t nargs)
 {
     if (nargs < 1 || nargs > kMaxInts + 1) {
-        PyErr_SetString(PyExc_TypeError, "call_ints(fn, up to 16 integer-class arguments)");
+        PyErr_SetString(PyExc_TypeError, "call_ints(fn, up to 20 integer-class arguments)");
         return nullptr;
     }
     const unsigned long long fn = PyLong_AsUnsignedLongLong(args[0]);
@@ -76,14 +77,14 @@ PyObject* call_ints(PyObject*, PyObject* const* args, Py_ssize_t nargs)
     uint64_t a[kMaxInts];
     if (!convert(args + 1, nargs - 1, a)) return nullptr;
     const int rc = reinterpret_cast<IntFn>(fn)(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12],
-                                               a[13], a[14], a[15]);
+                                               a[13], a[14], a[15], a[16], a[17], a[18], a[19]);
     return PyLong_FromLong(rc);
 }
 
 PyObject* call_f2(PyObject*, PyObject* const* args, Py_ssize_t nargs)
 {
     if (nargs < 3 || nargs > kMaxInts + 3) {
-        PyErr_SetString(PyExc_TypeError, "call_f2(fn, f0, f1, up to 16 integer-class arguments)");
+        PyErr_SetString(PyExc_TypeError, "call_f2(fn, f0, f1, up to 20 integer-class arguments)");
         return nullptr;
     }
     const unsigned long long fn = PyLong_AsUnsignedLongLong(args[0]);
@@ -93,7 +94,7 @@ PyObject* call_f2(PyObject*, PyObject* const* args, Py_ssize_t nargs)
     uint64_t a[kMaxInts];
     if (!convert(args + 3, nargs - 3, a)) return nullptr;
     const int rc = reinterpret_cast<F2Fn>(fn)((float)f0, (float)f1, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9],
-                                              a[10], a[11], a[12], a[13], a[14], a[15]);
+                                              a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[18], a[19]);
     return PyLong_FromLong(rc);
 }
 
