@@ -103,17 +103,21 @@ def main():
                       "reference_published_RTX5000Ada_ms": {"start_copy().get()": 0.375, "per-tensor .to()": 3.035, "speed-up": 8.10,
                                                             "source": "packages/multi_tensor_copier/docs/evaluation.rst:57-78"}}))
 
-    rows = {}
-    for pts, dist in ((2, 1), (100, 100), (1000, 1000), (5000, 5000)):
-        p = torch.rand(64, pts, 2, device=dev).cumsum(1)
-        d = torch.rand(64, dist, device=dev) * float(pts) * 0.5
-        rows[f"{pts} points x {dist} distances"] = per_call_us(lambda: interpolate(p, d), n=1000, warm=100)
-    print(json.dumps({"config": "lane_helpers.polyline.interpolate, batch 64", "this_build_MI355X": rows,
-                      "reference_published_RTX5000Ada_ms": {"2 x 1": 8.093e-3, "100 x 100": 4.731e-3, "1000 x 1000": 5.343e-3,
-                                                            "5000 x 5000": 2.230e-2,
-                                                            "source": "packages/lane_helpers/evaluation_results/polyline_runtime_evaluation/"
-                                                                      "batch_64_runtime_cuda.md"}}))
-
+    published = {1: {(2, 1): 0.003535, (100, 100): 0.003491, (1000, 1000): 0.003689, (2000, 2000): 0.005979, (5000, 5000): 0.0149,
+                     (5000, 1): 0.006, (2, 5000): 0.004911, (500, 5000): 0.007429},
+                 64: {(2, 1): 0.008093, (100, 100): 0.004731, (1000, 1000): 0.005343, (2000, 2000): 0.007966, (5000, 5000): 0.0223,
+                      (5000, 1): 0.007627, (2, 5000): 0.008322, (500, 5000): 0.009575}}
+    for batch, cells in published.items():
+        rows = {}
+        for (pts, dist), ref_ms in cells.items():
+            p = torch.rand(batch, pts, 2, device=dev).cumsum(1)
+            d = torch.rand(batch, dist, device=dev) * float(pts) * 0.5
+            r = per_call_us(lambda: interpolate(p, d), n=1000, warm=100)
+            r["published_us"] = round(ref_ms * 1e3, 2)
+            rows[f"{pts} points x {dist} distances"] = r
+        print(json.dumps({"config": f"lane_helpers.polyline.interpolate, batch {batch}", "this_build_MI355X": rows,
+                          "published_on": "RTX 5000 Ada",
+                          "source": f"packages/lane_helpers/evaluation_results/polyline_runtime_evaluation/batch_{batch}_runtime_cuda.md"}))
 
 if __name__ == "__main__":
     main()
