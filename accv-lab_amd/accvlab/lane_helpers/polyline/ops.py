@@ -12,6 +12,27 @@ import torch
 
 from ... import _amd_native as _nat
 
+try:  # C++ fast path of the fixed-size CUDA calls (built by `make -C accv-lab_amd/csrc_host`); the code below is complete without it
+    from . import _lane_host as _lh
+except ImportError:  # pragma: no cover
+    _lh = None
+_native_bound = False
+
+
+def _native():
+    """_lane_host with the C-ABI addresses bound (same library handle as the ctypes binding), or None."""
+    global _native_bound
+    if _lh is None:
+        return None
+    if not _native_bound:
+        import ctypes
+
+        h = _nat.ctypes_lib()
+        addr = lambda name: ctypes.cast(getattr(h, name), ctypes.c_void_p).value  # noqa: E731
+        _lh.bind_native(addr("accv_polyline_sample"), addr("accv_polyline_scratch_bytes"), addr("accv_last_error"))
+        _native_bound = True
+    return _lh
+
 _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.float16: 2, torch.bfloat16: 3}
 
 
@@ -189,6 +210,12 @@ def interpolate(points: torch.Tensor, distances: torch.Tensor, *, relative: bool
     """Sample every polyline of ``points (batch, num_points, num_dims)`` at ``distances (batch, num_distances)`` measured
     along the polyline from its first point (``relative=True``: as fractions of its total length).  Queries before the
     start / beyond the end clamp to the first / last point.  Returns ``(batch, num_distances, num_dims)``."""
+    if isinstance(points, torch.Tensor) and points.is_cuda and isinstance(distances, torch.Tensor):
+        native = _native()      # plain CUDA call: checks, allocation and the launch in C++ (declines anything unusual)
+        if native is not None:
+            res = native.interpolate(points, distances, bool(relative))
+            if res is not None:
+                return res
     _check_points(points)
     _check_points(distances, "distances")
     if not (points.dim() == 3):
@@ -208,6 +235,12 @@ def interpolate(points: torch.Tensor, distances: torch.Tensor, *, relative: bool
 
 def lengths(points: torch.Tensor) -> torch.Tensor:
     """Total length of every polyline of ``points (batch, num_points, num_dims)`` -> ``(batch,)``."""
+    if isinstance(points, torch.Tensor) and points.is_cuda:
+        native = _native()
+        if native is not None:
+            res = native.lengths(points)
+            if res is not None:
+                return res
     _check_points(points)
     if not (points.dim() == 3):
         raise RuntimeError("points must have shape (batch, num_points, num_dims)")
