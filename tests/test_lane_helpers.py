@@ -183,3 +183,34 @@ def test_native_host_path_matches_the_torch_formulation_and_the_oracle(dtype, re
     ref_l = ops._cpu_lengths(pts, n)
     assert torch.equal(torch.isnan(lens), torch.isnan(ref_l)) and float(torch.nan_to_num(lens - ref_l).abs().max()) <= tol * 20
     assert bool(torch.isnan(lens[0])) and float(lens[1]) == 0.0     # empty -> NaN, single point -> 0
+
+
+@pytest.mark.gpu
+def test_cpp_host_path_and_python_path_agree_and_unusual_inputs_fall_back(monkeypatch):
+    """interpolate / lengths on CUDA tensors go through csrc_host/lane_host.cpp; it must give what the python formulation of the
+    same call gives (bit for bit: same kernel), and decline — not mis-handle — what only the python path covers: non-contiguous
+    tensors, mismatching dtypes (RuntimeError with the reference's message)"""
+    import torch
+
+    from accvlab.lane_helpers.polyline import interpolate, lengths, ops
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(4)
+    for dt in (torch.float32, torch.float64, torch.float16, torch.bfloat16):
+        pts = (torch.rand(5, 9, 2, generator=g) * 10).to(dt).to(dev)
+        dist = (torch.rand(5, 7, generator=g) * 12).to(dt).to(dev)
+        assert ops._native() is not None, "build the host extensions (make -C accv-lab_amd/csrc_host)"
+        fast_i, fast_l = interpolate(pts, dist), lengths(pts)
+        fast_r = interpolate(pts, dist, relative=True)
+        with monkeypatch.context() as m:
+            m.setattr(ops, "_lh", None)
+            assert torch.equal(interpolate(pts, dist), fast_i) and torch.equal(lengths(pts), fast_l)
+            assert torch.equal(interpolate(pts, dist, relative=True), fast_r)
+        # non-contiguous points: declined by the C++ path, handled by the python one
+        wide = (torch.rand(5, 9, 4, generator=g) * 10).to(dt).to(dev)
+        nc = wide[:, :, :2]
+        assert not nc.is_contiguous() and torch.equal(interpolate(nc, dist), interpolate(nc.contiguous(), dist))
+    with pytest.raises(RuntimeError, match="same dtype"):
+        interpolate(torch.rand(2, 3, 2, device=dev), torch.rand(2, 4, device=dev, dtype=torch.float64))
+    with pytest.raises(RuntimeError):
+        interpolate(torch.rand(2, 3, 2, device=dev), torch.rand(3, 4, device=dev))
