@@ -12,6 +12,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ACCV_HIP_LIB points experiments (scripts/h1_variants.py) at another build, e.g. the A/B build `make tune`
+# ACCV_NO_HOST_FASTPATH=1: the operators keep to their python formulation (the C++ host fast paths of draw_heatmap_batched,
+# the ragged gather / scatter and the lane sampler decline everything) — used to run the test-suite over both
+NO_HOST_FASTPATH = os.environ.get("ACCV_NO_HOST_FASTPATH", "") not in ("", "0")
 LIB_PATH = os.environ.get("ACCV_HIP_LIB") or os.path.join(_HERE, "libaccv_hip.so")
 
 OK = 0

@@ -27,7 +27,7 @@ _native_bound = False
 def _native():
     """_bh_host with the C-ABI addresses bound (same library handle as the ctypes binding), or None."""
     global _native_bound
-    if _bh is None or not hasattr(_bh, "bind_native"):
+    if _bh is None or not hasattr(_bh, "bind_native") or _nat.NO_HOST_FASTPATH:
         return None
     if not _native_bound:
         import ctypes

@@ -15,6 +15,25 @@ import torch
 
 from .. import _amd_native as _nat
 
+try:  # C++ fast path of the plain draw_heatmap_batched call (built by `make -C accv-lab_amd/csrc_host`); complete without it
+    from . import _dh_host as _dh
+except ImportError:  # pragma: no cover
+    _dh = None
+_native_bound = False
+
+
+def _native():
+    """_dh_host with the C-ABI addresses bound (same library handle as the ctypes binding), or None."""
+    global _native_bound
+    if _dh is None or _nat.NO_HOST_FASTPATH:
+        return None
+    if not _native_bound:
+        h = _nat.ctypes_lib()
+        addr = lambda name: ctypes.cast(getattr(h, name), ctypes.c_void_p).value  # noqa: E731
+        _dh.bind_native(addr("accv_draw_heatmap_batched_f32"), addr("accv_last_error"))
+        _native_bound = True
+    return _dh
+
 
 # OR-ed into the flags of every draw_heatmap / draw_heatmap_batched call: lets the GPU test-suite run each test against
 # every kernel instantiation the public hints can select (tests/test_draw_heatmap_gpu.py); 0 in production
@@ -164,6 +183,14 @@ def draw_heatmap_batched(
         assert centers_t.shape[0] == labels_t.shape[0], "centers and labels must have the same size batch size"
         assert centers_t.shape[1] == labels_t.shape[1], \
             "centers and labels must have the same maximum number of objects"
+
+    # plain call (CUDA, contiguous, expected dtypes and extents): the launcher's checks and the launch in C++; anything else
+    # is declined there and takes the checks below, which raise the reference's errors
+    native = _native()
+    if native is not None and isinstance(heatmap, torch.Tensor) and isinstance(counts, torch.Tensor) and \
+            native.draw_batched(heatmap, centers_t, radii_t, counts, labels_t, float(diameter_to_sigma_factor), float(k_scale),
+                                _hint_flags(clear, small_radii, write_through, tile_rows)):
+        return
 
     # the reference casts to int32 with an extra kernel on every call (draw_heatmap_batched.py:63);
     # the C-ABI reads int32 or int64 counts directly

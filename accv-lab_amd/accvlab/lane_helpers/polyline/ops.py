@@ -22,7 +22,7 @@ _native_bound = False
 def _native():
     """_lane_host with the C-ABI addresses bound (same library handle as the ctypes binding), or None."""
     global _native_bound
-    if _lh is None:
+    if _lh is None or _nat.NO_HOST_FASTPATH:
         return None
     if not _native_bound:
         import ctypes

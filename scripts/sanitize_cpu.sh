@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # AddressSanitizer / UBSan over the HOST code of this repo on the CPU test suite (GPU sanitizers are not available on the
 # pool).  Two passes, because gcc's and clang's ASan run-times cannot share a process:
-#   1. the g++-built torch extensions (_mtc_host, _bh_host, _lane_host, _fastcall) with -fsanitize=address,undefined
+#   1. the g++-built torch extensions (_mtc_host, _bh_host, _lane_host, _dh_host, _fastcall) with -fsanitize=address,undefined
 #   2. the host side of libaccv_hip.so (pack planner, pinned arena, host pack / polyline paths, argument checks) with
 #      hipcc -Xarch_host -fsanitize=address, loaded through ACCV_HIP_LIB
 # The in-tree binaries are put back afterwards.  Usage: scripts/sanitize_cpu.sh [pytest args]
@@ -9,7 +9,7 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 PKG="$ROOT/accv-lab_amd"
 TMP="$(mktemp -d /tmp/accv_sanitize.XXXXXX)"
-EXTS=("$PKG"/accvlab/multi_tensor_copier/_mtc_host*.so "$PKG"/accvlab/batching_helpers/_bh_host*.so "$PKG"/accvlab/_amd_native/_fastcall*.so "$PKG"/accvlab/lane_helpers/polyline/_lane_host*.so)
+EXTS=("$PKG"/accvlab/multi_tensor_copier/_mtc_host*.so "$PKG"/accvlab/batching_helpers/_bh_host*.so "$PKG"/accvlab/_amd_native/_fastcall*.so "$PKG"/accvlab/lane_helpers/polyline/_lane_host*.so "$PKG"/accvlab/draw_heatmap/_dh_host*.so)
 mkdir -p "$TMP/keep" "$TMP/lib"
 for f in "${EXTS[@]}"; do cp -p "$f" "$TMP/keep/"; done
 restore() {
@@ -17,6 +17,7 @@ restore() {
     cp -p "$TMP"/keep/_bh_host*.so "$PKG/accvlab/batching_helpers/"
     cp -p "$TMP"/keep/_fastcall*.so "$PKG/accvlab/_amd_native/"
     cp -p "$TMP"/keep/_lane_host*.so "$PKG/accvlab/lane_helpers/polyline/"
+    cp -p "$TMP"/keep/_dh_host*.so "$PKG/accvlab/draw_heatmap/"
     rm -rf "$TMP"
 }
 trap restore EXIT
@@ -32,6 +33,7 @@ restore_only_exts() {
     cp -p "$TMP"/keep/_bh_host*.so "$PKG/accvlab/batching_helpers/"
     cp -p "$TMP"/keep/_fastcall*.so "$PKG/accvlab/_amd_native/"
     cp -p "$TMP"/keep/_lane_host*.so "$PKG/accvlab/lane_helpers/polyline/"
+    cp -p "$TMP"/keep/_dh_host*.so "$PKG/accvlab/draw_heatmap/"
 }
 restore_only_exts
 

@@ -517,3 +517,37 @@ def test_classwise_call_without_object_slots(clear):
     n = torch.zeros(2, dtype=torch.int64, device=DEV)
     draw_heatmap_batched(hm, rb(c, n), rb(r, n), labels=rb(torch.zeros((2, 0), dtype=torch.int32, device=DEV), n), clear=clear)
     assert float(hm.min()) == float(hm.max()) == (0.0 if clear else 0.25)
+
+
+def test_cpp_host_path_of_draw_heatmap_batched_agrees_with_the_python_path(monkeypatch):
+    """plain draw_heatmap_batched calls go through csrc_host/dh_host.cpp: same map as the python formulation of the call (batched
+    and class-wise, clear and in-place, int32 and int64 counts), and inputs it does not take (non-contiguous objects, a counts
+    dtype that needs a cast) reach the python path instead of being mis-handled"""
+    from accvlab import _amd_native as nat
+    from accvlab.draw_heatmap import ops
+
+    if nat.NO_HOST_FASTPATH:
+        pytest.skip("ACCV_NO_HOST_FASTPATH=1: the suite is running over the python formulations only")
+    assert ops._native() is not None, "build the host extensions (make -C accv-lab_amd/csrc_host)"
+    _, draw_heatmap_batched = _dh()
+    g = torch.Generator().manual_seed(9)
+    b, n, h, w, ncls = 3, 7, 40, 72, 4
+    c = torch.stack([torch.randint(0, w, (b, n), generator=g), torch.randint(0, h, (b, n), generator=g)], -1).to(torch.int32).to(DEV)
+    r = torch.randint(0, 9, (b, n), generator=g).to(torch.int32).to(DEV)
+    lab = torch.randint(0, ncls, (b, n), generator=g).to(torch.int32).to(DEV)
+    for cnt in (torch.tensor([7, 0, 3]), torch.tensor([7, 0, 3], dtype=torch.int32), torch.tensor([7, 0, 3], dtype=torch.int16)):
+        cnt = cnt.to(DEV)
+        for clear in (True, False):
+            base, base_cw = torch.rand(b, h, w, generator=g).to(DEV) * 0.3, torch.rand(b, ncls, h, w, generator=g).to(DEV) * 0.3
+            fast, fast_cw = base.clone(), base_cw.clone()
+            draw_heatmap_batched(fast, rb(c, cnt), rb(r, cnt), 6.0, 0.9, clear=clear)
+            draw_heatmap_batched(fast_cw, rb(c, cnt), rb(r, cnt), 6.0, 0.9, labels=rb(lab, cnt), clear=clear)
+            with monkeypatch.context() as m:
+                m.setattr(ops, "_dh", None)
+                slow, slow_cw = base.clone(), base_cw.clone()
+                draw_heatmap_batched(slow, rb(c, cnt), rb(r, cnt), 6.0, 0.9, clear=clear)
+                draw_heatmap_batched(slow_cw, rb(c, cnt), rb(r, cnt), 6.0, 0.9, labels=rb(lab, cnt), clear=clear)
+            assert torch.equal(fast, slow) and torch.equal(fast_cw, slow_cw)
+    with pytest.raises(RuntimeError):        # non-contiguous centres: declined in C++, diagnosed by the python checks
+        wide = torch.zeros(b, n, 4, dtype=torch.int32, device=DEV)
+        draw_heatmap_batched(torch.zeros(b, h, w, device=DEV), rb(wide[:, :, :2], cnt.to(torch.int64)), rb(r, cnt.to(torch.int64)))
