@@ -86,7 +86,10 @@ def main():
     res["combine_data(64 CPU samples -> cuda)"] = rate(lambda: combine_data(boxes_cpu, device=dev), n=500)
     res["combine_data(64 CUDA samples)"] = rate(lambda: combine_data(boxes_gpu), n=500)
     rb = combine_data(boxes_gpu)
-    res["RaggedBatch.split (64 CUDA samples; sizes known on the host: no read-back)"] = rate(lambda: rb.split(), n=500)
+    # (measured twice, the smaller value reported: the first measurement right behind the 700 combine_data calls above reads
+    # ~100 us, every later one 10-13 us — also in isolation)
+    res["RaggedBatch.split (64 CUDA samples; sizes known on the host: no read-back)"] = min(rate(lambda: rb.split(), n=500),
+                                                                                             rate(lambda: rb.split(), n=500))
     print(json.dumps({k: round(v, 2) for k, v in res.items()}, indent=1))
 
 
