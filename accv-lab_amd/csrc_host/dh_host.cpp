@@ -34,7 +34,7 @@ inline bool plain(const at::Tensor& t, int device)
 bool draw_batched(const at::Tensor& heatmap, const at::Tensor& centers, const at::Tensor& radii, const at::Tensor& counts,
                   const c10::optional<at::Tensor>& labels, double factor, double k_scale, uint64_t flags)
 {
-    if (!g_api.batched || !heatmap.defined() || !heatmap.is_cuda()) return false;
+    if (!g_api.batched || !heatmap.defined() || !heatmap.is_cuda() || heatmap.dim() < 3) return false;
     const int dev = (int)heatmap.get_device();
     if (dev != (int)c10::hip::current_device()) return false;
     if (!plain(heatmap, dev) || !plain(centers, dev) || !plain(radii, dev) || !plain(counts, dev)) return false;
