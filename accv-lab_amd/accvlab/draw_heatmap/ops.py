@@ -73,6 +73,34 @@ def _same_device(ref: torch.Tensor, *others) -> None:
             raise RuntimeError(f"{name} must be on the same device as the heatmap ({ref.device})")
 
 
+_FLAT_DIRECT_MAX_OBJECTS = 2048
+_FLAT_DIRECT_MAX_ROUNDS = 200_000     # tiles x cull rounds of 64 objects: ~8 M wave instructions, a few microseconds of the chip
+_count_cache = {}
+
+
+def _flat_direct(planes: int, height: int, width: int, n: int) -> bool:
+    if not (0 < n <= _FLAT_DIRECT_MAX_OBJECTS and 0 < planes <= 65535 and height > 0 and width > 0):
+        return False
+    tiles = planes * ((width + 127) // 128) * ((height + 15) // 16)
+    return tiles * ((n + 63) // 64) <= _FLAT_DIRECT_MAX_ROUNDS
+
+
+def _one_count(n: int, device) -> torch.Tensor:
+    """int32 [1] = n on `device`, shared by later calls on any stream (created once: its stream is drained before it is
+    published; nothing is cached while a stream is being captured)."""
+    key = (n, device)
+    t = _count_cache.get(key)
+    if t is None:
+        t = torch.full((1,), n, dtype=torch.int32, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            return t
+        torch.cuda.current_stream(device).synchronize()
+        if len(_count_cache) > 256:
+            _count_cache.clear()
+        _count_cache[key] = t
+    return t
+
+
 def draw_heatmap(
     heatmaps: torch.Tensor,
     centers: torch.Tensor,
@@ -128,6 +156,19 @@ def draw_heatmap(
     lib = _nat.lib()
     planes, height, width = heatmaps.shape
     n = centers.size(0)
+    if _flat_direct(planes, height, width, n):
+        # few objects: ONE launch.  The flat input is the class-wise batched call with a single sample whose "classes" are
+        # the planes (plane = label; labels outside [0, P) match no plane, i.e. such objects are ignored, as in the flat
+        # entry point): every tile tests all N objects instead of its plane's share, which costs less than the binning
+        # launch while N is small.  Same values (max is order independent).
+        with _nat.device_guard(heatmaps.device):
+            count = _one_count(n, heatmaps.device)
+            status = lib.accv_draw_heatmap_batched_f32(
+                heatmaps.data_ptr(), 1, planes, height, width, centers.data_ptr(), radii.data_ptr(), count.data_ptr(),
+                heatmap_idxes.data_ptr(), n, float(diameter_to_sigma_factor), float(k_scale),
+                _hint_flags(clear, small_radii, write_through, tile_rows), _nat.stream_ptr(heatmaps.device))
+        _nat.check(status, "draw_heatmap")
+        return
     with _nat.device_guard(heatmaps.device):
         ws_bytes = lib.accv_draw_heatmap_flat_workspace_bytes(planes, n)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=heatmaps.device)
