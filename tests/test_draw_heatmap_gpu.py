@@ -551,3 +551,32 @@ def test_cpp_host_path_of_draw_heatmap_batched_agrees_with_the_python_path(monke
     with pytest.raises(RuntimeError):        # non-contiguous centres: declined in C++, diagnosed by the python checks
         wide = torch.zeros(b, n, 4, dtype=torch.int32, device=DEV)
         draw_heatmap_batched(torch.zeros(b, h, w, device=DEV), rb(wide[:, :, :2], cnt.to(torch.int64)), rb(r, cnt.to(torch.int64)))
+
+
+@pytest.mark.parametrize("clear", [True, False])
+def test_flat_call_single_launch_and_binned_paths_agree(clear, monkeypatch):
+    """draw_heatmap with few objects runs as ONE launch (the flat input as a one-sample class-wise call); with many it bins the
+    objects per plane first.  Same maps, incl. objects whose plane index is out of range (ignored by both)."""
+    from accvlab import _amd_native as nat
+    from accvlab.draw_heatmap import ops
+
+    draw_heatmap, _ = _dh()
+    g = torch.Generator().manual_seed(31)
+    p, h, w, n = 7, 48, 200, 300
+    c = torch.stack([torch.randint(-5, w + 5, (n,), generator=g), torch.randint(-5, h + 5, (n,), generator=g)], -1).to(torch.int32).to(DEV)
+    r = torch.randint(-1, 12, (n,), generator=g).to(torch.int32).to(DEV)
+    idx = torch.randint(-2, p + 2, (n,), generator=g).to(torch.int32).to(DEV)
+    base = (torch.rand(p, h, w, generator=g) * 0.3).to(DEV)
+    direct = base.clone()
+    draw_heatmap(direct, c, r, idx, 6.0, 0.8, clear=clear)
+    kernel_direct = nat.last_dispatch()
+    monkeypatch.setattr(ops, "_FLAT_DIRECT_MAX_OBJECTS", 0)
+    binned = base.clone()
+    draw_heatmap(binned, c, r, idx, 6.0, 0.8, clear=clear)
+    assert torch.equal(direct, binned)
+    assert f",{p}) block(64)" in kernel_direct                      # one plane per "class" of the single sample
+    want = base.cpu().numpy().copy()
+    if clear:
+        want[:] = 0
+    oracle.draw_heatmap_flat(want, c.cpu().numpy(), r.cpu().numpy(), idx.cpu().numpy(), 6.0, 0.8)
+    _close(direct, want, "flat, single launch")
