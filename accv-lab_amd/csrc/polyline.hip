@@ -99,14 +99,16 @@ __device__ __forceinline__ long long load_count(const void* p, long long i, int 
     return is64 ? static_cast<const long long*>(p)[i] : (long long)static_cast<const int*>(p)[i];
 }
 
-template <int TY>
-__global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
+// THREADS = workgroup size: 256, or 1024 for long polylines (the scan over the points is the serial part of a workgroup)
+template <int TY, int THREADS>
+__global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
 {
+    constexpr int kPerLane = THREADS / 64;   // chunk totals per lane in the scan by wave 0
     using S = Storage<TY>;
     using T = typename S::T;
     using Acc = typename S::Acc;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ Acc s_part[kThreads];
+    __shared__ Acc s_part[THREADS];
 
     const long long b = blockIdx.x;
     const int t = threadIdx.x;
@@ -125,12 +127,12 @@ __global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
 
     if (n == 0) {  // undefined polyline: NaN everywhere (polyline_kernels.cuh:216-225)
         if (out)
-            for (int i = q_begin * p.D + t; i < q_stop * p.D; i += kThreads) S::store(out + i, nan);
+            for (int i = q_begin * p.D + t; i < q_stop * p.D; i += THREADS) S::store(out + i, nan);
         if (p.out_lengths && t == 0 && first_chunk) S::store(static_cast<T*>(p.out_lengths) + b, nan);
         if (p.out_boxes) {
             const int groups = (p.Q + 63) / 64;
             const float inf = __builtin_inff();
-            for (int g = (q_begin >> 6) + t; g < min(groups, (q_cap + 63) >> 6); g += kThreads)
+            for (int g = (q_begin >> 6) + t; g < min(groups, (q_cap + 63) >> 6); g += THREADS)
                 reinterpret_cast<float4*>(p.out_boxes)[b * groups + g] = make_float4(inf, inf, -inf, -inf);
         }
         return;
@@ -140,18 +142,18 @@ __global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
 
     // ---- segment lengths, chunked: thread t owns segments [lo, hi), writes the chunk-local inclusive prefix
     const int n_seg = n - 1;
-    const int per = (n_seg + kThreads - 1) / kThreads;
+    const int per = (n_seg + THREADS - 1) / THREADS;
     const int lo = min(t * per, n_seg), hi = min(lo + per, n_seg);
     // (lengths first, with consecutive threads on consecutive segments — coalesced reads of the points; a thread walking its
     // own chunk of the points made every wave load touch 64 different cache lines: 5000 points took 15 us)
     // four segments per thread and trip, their loads issued together: the loop is a chain of memory round trips otherwise
     // (20 trips of ~0.5 us for 5000 points)
     constexpr int kBatch = 4;
-    for (int s0 = t; s0 < n_seg; s0 += kBatch * kThreads) {
+    for (int s0 = t; s0 < n_seg; s0 += kBatch * THREADS) {
         Acc sq[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-            const int s = min(s0 + u * kThreads, n_seg - 1);      // clamped: loads stay in range, surplus results are dropped
+            const int s = min(s0 + u * THREADS, n_seg - 1);      // clamped: loads stay in range, surplus results are dropped
             Acc acc2 = 0;
             for (int d = 0; d < p.D; ++d) {
                 const Acc diff = S::load(pts + (size_t)s * p.D + d) - S::load(pts + (size_t)(s + 1) * p.D + d);
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
         }
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-            const int s = s0 + u * kThreads;
+            const int s = s0 + u * THREADS;
             if (s < n_seg) accum[s + 1] = sqrt(sq[u]);
         }
     }
@@ -175,21 +177,27 @@ __global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
     if (t == 0) accum[0] = 0;
     s_part[t] = run;
     __syncthreads();
-    // ---- exclusive scan of the 256 chunk totals by wave 0 (4 per lane + 64-lane shuffle scan)
+    // ---- exclusive scan of the THREADS chunk totals by wave 0 (kPerLane per lane + 64-lane shuffle scan)
     if (t < 64) {
-        Acc v0 = s_part[4 * t], v1 = s_part[4 * t + 1], v2 = s_part[4 * t + 2], v3 = s_part[4 * t + 3];
-        const Acc lane_total = v0 + v1 + v2 + v3;
+        Acc v[kPerLane];
+        Acc lane_total = 0;
+#pragma unroll
+        for (int u = 0; u < kPerLane; ++u) {
+            v[u] = s_part[kPerLane * t + u];
+            lane_total += v[u];
+        }
         Acc incl = lane_total;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const Acc up = __shfl_up(incl, off, 64);
             if (t >= off) incl += up;
         }
-        const Acc excl = incl - lane_total;
-        s_part[4 * t] = excl;
-        s_part[4 * t + 1] = excl + v0;
-        s_part[4 * t + 2] = excl + v0 + v1;
-        s_part[4 * t + 3] = excl + v0 + v1 + v2;
+        Acc run2 = incl - lane_total;
+#pragma unroll
+        for (int u = 0; u < kPerLane; ++u) {
+            s_part[kPerLane * t + u] = run2;
+            run2 += v[u];
+        }
     }
     __syncthreads();
     const Acc base = s_part[t];
@@ -207,9 +215,9 @@ __global__ __launch_bounds__(kThreads) void polyline_kernel(const PolyParams p)
     const Acc eps = std::numeric_limits<Acc>::epsilon();
     // (whole waves walk the loop together: when group boxes are wanted, the 64 lanes of a wave hold 64 consecutive samples
     // and reduce their bounding box with shuffles)
-    const int q_span = p.out_boxes ? q_begin + ((q_cap - q_begin + kThreads - 1) / kThreads) * kThreads : q_stop;
+    const int q_span = p.out_boxes ? q_begin + ((q_cap - q_begin + THREADS - 1) / THREADS) * THREADS : q_stop;
     const int groups = (p.Q + 63) / 64;
-    for (int i = q_begin + t; i < q_span; i += kThreads) {
+    for (int i = q_begin + t; i < q_span; i += THREADS) {
         float bx = __builtin_nanf(""), by = bx;  // sample coordinates for the group box (D == 2, f32 instantiation)
         if (i < q_stop) {
             Acc d = S::load(dist + i);
@@ -327,22 +335,34 @@ int accv_polyline_sample_boxes(const void* points, const void* distances, const 
     // queries per workgroup: everything, unless few polylines carry thousands of queries each — then the queries of a polyline
     // are cut into chunks (multiples of the workgroup size, so that groups of 64 samples never straddle a chunk), as many as
     // keep the launch at <= ~4096 workgroups (batch 64, 5000 x 5000: 50 us with one workgroup per polyline; profiles/r02_bench_published.jsonl)
+    // long polylines take 1024-thread workgroups: the scan over the points is the serial part of a workgroup (5000 points:
+    // 20 segments per thread with 256 threads, 5 with 1024)
+    const bool wide = max_points >= 2048;
+    const long long threads = wide ? 1024 : kThreads;
     long long chunks = 1;
     // (every chunk repeats the scan over max_points, so a chunk should hold at least ~max_points / 4 queries)
-    const long long min_chunk = std::max<long long>(kThreads, ((max_points / 4 + kThreads - 1) / kThreads) * kThreads);
+    const long long min_chunk = std::max<long long>(threads, ((max_points / 4 + threads - 1) / threads) * threads);
     if (p.out_points && !p.use_scratch && max_distances >= 2 * min_chunk && batch < 2048)
         chunks = std::max<long long>(1, std::min<long long>((max_distances + min_chunk - 1) / min_chunk, 4096 / batch));
     const long long per_chunk = (max_distances + chunks - 1) / chunks;
-    p.q_chunk = (int)std::min<long long>(((per_chunk + kThreads - 1) / kThreads) * kThreads, (long long)INT_MAX - kThreads);
-    if (p.q_chunk < kThreads) p.q_chunk = kThreads;
+    p.q_chunk = (int)std::min<long long>(((per_chunk + threads - 1) / threads) * threads, (long long)INT_MAX - threads);
+    if (p.q_chunk < threads) p.q_chunk = (int)threads;
     chunks = std::max<long long>(1, ((long long)max_distances + p.q_chunk - 1) / p.q_chunk);
-    const dim3 grid((unsigned)batch, (unsigned)chunks), block(kThreads);
+    const dim3 grid((unsigned)batch, (unsigned)chunks), block((unsigned)threads);
+#define ACCV_LAUNCH_POLY(TYV)                                                                               \
+    do {                                                                                                    \
+        if (wide)                                                                                           \
+            hipLaunchKernelGGL((polyline_kernel<TYV, 1024>), grid, block, lds, stream, p);                  \
+        else                                                                                                \
+            hipLaunchKernelGGL((polyline_kernel<TYV, kThreads>), grid, block, lds, stream, p);              \
+    } while (0)
     switch (dtype) {
-        case kPF32: hipLaunchKernelGGL((polyline_kernel<kPF32>), grid, block, lds, stream, p); break;
-        case kPF64: hipLaunchKernelGGL((polyline_kernel<kPF64>), grid, block, lds, stream, p); break;
-        case kPF16: hipLaunchKernelGGL((polyline_kernel<kPF16>), grid, block, lds, stream, p); break;
-        default: hipLaunchKernelGGL((polyline_kernel<kPBF16>), grid, block, lds, stream, p); break;
+        case kPF32: ACCV_LAUNCH_POLY(kPF32); break;
+        case kPF64: ACCV_LAUNCH_POLY(kPF64); break;
+        case kPF16: ACCV_LAUNCH_POLY(kPF16); break;
+        default: ACCV_LAUNCH_POLY(kPBF16); break;
     }
+#undef ACCV_LAUNCH_POLY
     return accv::check_launch("polyline");
 }
 

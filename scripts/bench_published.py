@@ -23,7 +23,14 @@ import bench_workloads as wl  # noqa: E402
 
 
 def per_call_us(fn, n=2000, warm=200):
-    """back-to-back calls: what a training loop pays per call (the larger of host and device time)"""
+    """back-to-back calls: what a training loop pays per call (the larger of host and device time); measured twice, the faster
+    pass reported (the first pass behind a section with many allocations occasionally reads 2x slow)"""
+    a = _per_call_us(fn, n, warm)
+    b = _per_call_us(fn, n, 0)
+    return a if a["wall_us"] <= b["wall_us"] else b
+
+
+def _per_call_us(fn, n, warm):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
