@@ -217,3 +217,40 @@ def test_cpp_host_path_and_python_path_agree_and_unusual_inputs_fall_back(monkey
         interpolate(torch.rand(2, 3, 2, device=dev), torch.rand(2, 4, device=dev, dtype=torch.float64))
     with pytest.raises(RuntimeError):
         interpolate(torch.rand(2, 3, 2, device=dev), torch.rand(3, 4, device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npnt,nq", [(10, 3000), (600, 5000), (3000, 4100), (2048, 9000)])
+def test_gpu_many_queries_are_chunked_over_workgroups(npnt, nq):
+    """few polylines x thousands of queries: the queries of a polyline are spread over several workgroups (each repeats the
+    scan; 1024-thread workgroups from 2048 points on) — fixed and ragged, relative, and the group boxes written alongside"""
+    from accvlab.batching_helpers import RaggedBatch
+    from accvlab.draw_heatmap import sample_lanes
+
+    poly = _poly()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(npnt + nq)
+    b = 3
+    p = torch.rand((b, npnt, 2), generator=g, dtype=torch.float64) * 3
+    tot = torch.linalg.vector_norm(p[:, 1:] - p[:, :-1], dim=2).sum(1)
+    d = (torch.rand((b, nq), generator=g, dtype=torch.float64) * 1.2 - 0.1) * tot[:, None]
+    ref = np.stack([oracle.sample(p[i].numpy(), d[i].numpy()) for i in range(b)])
+    got = poly.interpolate(p.to(dev), d.to(dev))
+    assert np.allclose(got.cpu().numpy(), ref, atol=1e-9, rtol=0)
+    rel = poly.interpolate(p.to(dev), (d / tot[:, None]).to(dev), relative=True)
+    assert np.allclose(rel.cpu().numpy(), ref, atol=1e-8, rtol=0)
+    n_p = torch.tensor([npnt, max(1, npnt // 3), 0])
+    n_q = torch.tensor([nq, nq // 2 + 7, nq - 1])
+    rg = poly.interpolate_var_size_batch(RaggedBatch(p.to(dev), sample_sizes=n_p.to(dev)), RaggedBatch(d.to(dev), sample_sizes=n_q.to(dev)))
+    for i in range(b):
+        want = oracle.sample(p[i, : n_p[i]].numpy(), d[i, : n_q[i]].numpy())
+        assert np.allclose(rg.tensor[i, : n_q[i]].cpu().numpy(), want, atol=1e-9, rtol=0, equal_nan=True)
+    # the sampler of the lane raster with its group boxes (float32, 2-D): one box per 64 consecutive samples
+    q = (nq // 64) * 64
+    lanes = p.float().view(1, b, npnt, 2).to(dev)
+    boxes = torch.empty(1 * ((b * q + 63) // 64) * 4 + 4, device=dev)
+    samples = sample_lanes(lanes, q, group_boxes_ptr=boxes.data_ptr())
+    torch.cuda.synchronize()
+    grp = samples.view(b * q // 64, 64, 2)
+    want_boxes = torch.cat([grp.min(1).values, grp.max(1).values], 1)
+    assert torch.equal(boxes[: want_boxes.numel()].view(-1, 4), want_boxes)
