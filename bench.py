@@ -266,11 +266,11 @@ def main():
         step()
     # the box's clock / power state, sampled with work in the queue.  The sysfs reads take ~0.1 s during which the queue runs
     # dry, so this comes BEFORE the pre-warm, never between the pre-warm and the timed region
-    env = None
-    if rank == 0:
-        for _ in range(300):
-            step()
-        env = device_env(dev_index)
+    # (every rank does it, so that all ranks reach the pre-warm and the opening barrier of the timed region together; rank 0
+    # reports its sample)
+    for _ in range(300):
+        step()
+    env = device_env(dev_index)
     # extra untimed pre-warm: the chip needs ~15 ms of back-to-back launches after an idle/sync before kernel times
     # settle (profiles/r01_rocprof: 109 -> 128 -> 97 us); keep the queue full for >= 100 ms right up to the timed region
     sync()
