@@ -27,6 +27,9 @@ HM_TILE_ROWS_16 = 32
 HM_TILE_ROWS_8 = 64
 HM_CALLER_SCALE_ORDER = 256
 HM_PLAIN_STORES = 128
+MP_IDX_I64 = 1
+MP_COUNTS_I64 = 2
+MP_LABELS_I64 = 4
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -67,6 +70,9 @@ SIGNATURES = {
     "accv_matched_pair_reduce_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _f, _i, _i, _vp, _vp]),
     "accv_matched_pair_reduce_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _f, _i, _i,
                                               _vp, _vp, _vp, _vp]),
+    "accv_matched_pair_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _i, _f, _f, _u, _vp, _vp]),
+    "accv_matched_pair_reduce_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _ll, _i, _i, _f, _f, _u,
+                                          _vp, _vp, _vp, _vp]),
     # H3 multi-tensor copier
     "accv_mtc_plan": (_i, [_ll, _vp, _vp, _vp, _ll, _ll, _vp, _vp, _vp, _vp]),
     "accv_pinned_acquire": (_vp, [_sz]),
@@ -79,6 +85,8 @@ SIGNATURES = {
     "accv_mtc_stage_h2d_async": (_i, [_ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "accv_mtc_async_wait": (_i, [_ll]),
     "accv_mtc_async_poll": (_i, [_ll]),
+    "accv_mtc_shutdown": (None, []),
+    "accv_mtc_async_tickets_held": (_ll, []),
     "accv_mtc_coalesce": (_i, [_vp, _ll, _vp, _i, _vp]),
     "accv_memcpy_async": (_i, [_vp, _vp, _sz, _i, _vp]),
     # lane_helpers

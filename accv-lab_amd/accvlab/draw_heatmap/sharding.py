@@ -126,3 +126,26 @@ def job_throughput(units_per_rank: int, world: int, ms_per_step_max: float) -> f
     """Whole-job units per second: every rank processed ``units_per_rank`` per step, the step took the slowest
     rank's time."""
     return world * units_per_rank / (ms_per_step_max * 1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Strong scaling (SURVEY §8e, config C4): ONE batch of `total` frames is cut contiguously over the ranks
+# (64 -> 64 / 32 / 16 / 8 frames per GPU at 1 / 2 / 4 / 8 GPUs); every rank draws only its slice.
+def strong_scaling_run(make_step, total: int, rank: int, world: int, steps: int, warmup: int, dist=None, sync=None,
+                       device=None) -> dict:
+    """Time ``steps`` draws of this rank's :func:`shard_range` slice of a ``total``-frame batch between the same barrier
+    brackets as the weak mode and reduce with MAX over ranks.
+
+    ``make_step(begin, end)`` returns the callable that draws frames ``[begin, end)`` (called once, outside the timed
+    region); a rank with an empty slice (``world > total``) only takes part in the barriers.  Returns the per-rank and
+    whole-job figures; ``frames_per_s`` = ``total`` / slowest rank's time per step.
+    """
+    begin, end = shard_range(total, rank, world)
+    step = make_step(begin, end) if end > begin else (lambda: None)
+    for _ in range(max(0, int(warmup))):
+        step()
+    ms = timed_steps(step, steps, dist=dist, sync=sync)
+    ms_max = max_over_ranks(ms, device=device)
+    return {"total_frames": int(total), "frames_this_rank": end - begin, "range_this_rank": [begin, end],
+            "frames_per_rank": [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)],
+            "ms_this_rank": ms, "ms_per_step": ms_max, "frames_per_s": total / (ms_max * 1e-3), "steps": int(steps)}

@@ -298,11 +298,27 @@ def _start_native_h2d(job: _Job) -> bool:
             job.events.append(done)
             job.pending_views = prep["views"]
             return True
+        _register_native_shutdown()
         ticket = ctypes.c_longlong(0)
         _nat.check(lib.accv_mtc_stage_h2d_async(*prep["stage_args"], side.cuda_stream, 0, job.device.index,
                                                 ctypes.addressof(ticket)), "mtc_stage_h2d_async")
     job.ticket, job.pending_views, job.side = int(ticket.value), prep["views"], side
     return True
+
+
+_shutdown_registered = False
+
+
+def _register_native_shutdown() -> None:
+    """The library's orchestration thread is stopped from ``atexit`` — i.e. while the HIP runtime is still alive — instead
+    of from a static destructor after it (the reference joins its CopyThreadPool in the pool's destructor,
+    multi_tensor_copier.cpp:300-312)."""
+    global _shutdown_registered
+    if not _shutdown_registered:
+        import atexit
+
+        atexit.register(lambda: _nat.ctypes_lib().accv_mtc_shutdown())
+        _shutdown_registered = True
 
 
 def _run(job: _Job) -> None:
@@ -641,15 +657,20 @@ def start_copy(data, device, *, use_pinned_staging: bool = True, pack_cpu_tensor
 
     The inputs must stay alive and unmodified until ``get()`` returned or ``ready()`` was True.
     """
-    dev = torch.device(device)  # RuntimeError on malformed strings (reference :225-232)
+    try:
+        dev = torch.device(device)
+    except RuntimeError as exc:
+        # the extension's own text for a malformed device (multi_tensor_copier.cpp:225-232: parse_device turns the
+        # c10::Error into this message); torch's explanation stays attached as the cause
+        raise RuntimeError(f"Invalid device string: '{device}'") from exc
     if dev.type == "cuda":
         if not torch.cuda.is_available():
-            raise RuntimeError(f"Invalid device string: {device!r} (no GPU is available)")
+            raise RuntimeError(f"Invalid device string: '{device}' (no GPU is available)")
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         _nat.lib()  # fail loudly if the HIP library is missing
     elif dev.type != "cpu":
-        raise RuntimeError(f"Invalid device string: {device!r}")
+        raise RuntimeError(f"Invalid device string: '{device}'")
     from .packed import PackedBatch
 
     packed = data if isinstance(data, PackedBatch) else None

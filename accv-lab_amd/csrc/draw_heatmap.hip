@@ -461,11 +461,10 @@ template <bool CLEAR, int SM, int SRC, int NW = 1>
 __device__ __forceinline__ void small_body(const SplatParams& p, long long linear_group)
 {
     constexpr int TW = 128, TH = 16;
-    constexpr int RPW = TH / NW / 2;  // rows per half-wave in the init / read-back passes
+    constexpr int RPW = TH / NW / 2;  // rows per half-wave in the zero / init / read-back passes
     static_assert(TH % (2 * NW) == 0, "rows must split evenly over the half-waves of the workgroup");
     __shared__ Hit s_hit[NW][kCand];
     __shared__ __attribute__((aligned(16))) float s_tile[TH][TW];
-    __shared__ int s_touched;
 
     const int lane = threadIdx.x & 63;
     const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
@@ -473,26 +472,59 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
     if (!locate_tile<TW, TH, 1>(p, 0, t, linear_group)) return;  // uniform over the workgroup
     const int sub = lane >> 5, col0 = t.tx0 + (lane & 31) * 4;
     const int row0 = wave * (TH / NW) + sub * RPW;               // first of this half-wave's rows
+    float* plane_ptr = p.hm + (size_t)t.plane * (size_t)p.H * (size_t)p.W;
 
-    // "untouched" is -inf in the LDS tile (fused-clear mode starts from 0 = the cleared map)
-    const float init = CLEAR ? 0.0f : -__builtin_inff();
+    // Round 3: the splats of a lane raster cover a few per cent of the map, and most tiles see no sample at all, so a
+    // fused-clear launch is first of all a FILL.  Every lane stores the zeros of its own 16-byte segments right away —
+    // behind the first (independent) loads of the cull, so that those do not queue behind the stores — and the tile is
+    // only set up in LDS, splatted and written a second time where a sample actually reaches it.  The second store of
+    // a segment comes from the SAME lane as its zeros (program order on one address), and only segments that received a
+    // value are written again: an untouched tile costs two store instructions per wave, no LDS, no barrier, and its
+    // wave never waits for a load it issued after the stores.
+    auto store_segment = [&](int row, const vfloat4& v) {
+        if constexpr (SM >= 2) {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, 18);
+        } else {
+            *reinterpret_cast<vfloat4*>(plane_ptr + (size_t)row * p.W + col0) = v;
+        }
+    };
+    auto store_zeros = [&]() {
+        if constexpr (CLEAR) {
+            if (col0 < p.W) {
 #pragma unroll
-    for (int i = 0; i < RPW; ++i)
-        *reinterpret_cast<vfloat4*>(&s_tile[row0 + i][(lane & 31) * 4]) = vfloat4{init, init, init, init};
-    if constexpr (NW > 1) {
-        if (threadIdx.x == 0) s_touched = 0;
-        __syncthreads();  // tile initialised by all waves before the first atomic of any
-    } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile initialised before the first atomic
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+                for (int i = 0; i < RPW; ++i) {
+                    const int row = t.ty0 + row0 + i;
+                    if (row < p.H) store_segment(row, vfloat4{0.0f, 0.0f, 0.0f, 0.0f});
+                }
+            }
+        }
+    };
 
-    int total_hits = 0;
+    // "untouched" is -inf in the LDS tile (fused-clear mode starts from 0 = the cleared map).  The tile is initialised
+    // lazily, at the first sample (group) that can reach it: the condition is uniform over the workgroup
+    const float init = CLEAR ? 0.0f : -__builtin_inff();
+    bool tile_ready = false;
+    auto prepare_tile = [&]() {
+        if (tile_ready) return;
+        tile_ready = true;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+            *reinterpret_cast<vfloat4*>(&s_tile[row0 + i][(lane & 31) * 4]) = vfloat4{init, init, init, init};
+        if constexpr (NW > 1) {
+            __syncthreads();  // tile initialised by all waves before the first atomic of any
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile initialised before the first atomic
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
+
     // one cull round over the 64 candidates [sub_base, sub_base + 64): compaction, then the hits' boxes are walked
     auto process_round = [&](int sub_base, const Cand& cand) {
         const unsigned long long m = cull_test(t, sub_base, lane, cand);
         const int nh = __popcll(m);
         if (nh == 0) return;
+        if constexpr (NW == 1) prepare_tile();   // (NW > 1: the caller prepared it — a barrier must not sit in per-wave flow)
         if ((m >> lane) & 1ull) s_hit[wave][__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, cand.x, cand.y, cand.r);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -521,7 +553,6 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         // the next round overwrites the hit list: order it behind this round's reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        total_hits += nh;
     };
 
     if constexpr (SRC == 2) {
@@ -529,22 +560,27 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         // bounding box (group_boxes_kernel); a lane tests one GROUP, and only groups that can reach the tile are
         // walked candidate by candidate — a tile crossed by a lane visits 1-3 rounds instead of all of them
         constexpr float kClampF = 536870912.0f;  // 2^29, as in the integer cull
+        const float inf = __builtin_inff();
+        auto load_group_box = [&](int g) {
+            return (g < p.n_groups && g * kCand < t.n) ? t.boxes_f[g] : float4{inf, inf, -inf, -inf};
+        };
+        const float4 first_boxes = load_group_box(lane);   // issued BEFORE the zero stores
+        store_zeros();
         for (int g0 = 0; g0 < p.n_groups; g0 += kCand) {
-            const int g = g0 + lane;
+            const float4 b = g0 == 0 ? first_boxes : load_group_box(g0 + lane);
             bool ghit = false;
-            if (g < p.n_groups && g * kCand < t.n) {
-                const float4 b = t.boxes_f[g];
-                if (b.x <= b.z) {  // not empty (a group of NaN points keeps xmin = +inf)
-                    const int cx0 = (int)fminf(fmaxf(__fdiv_rn(b.x, t.stride), -kClampF), kClampF);
-                    const int cy0 = (int)fminf(fmaxf(__fdiv_rn(b.y, t.stride), -kClampF), kClampF);
-                    const int cx1 = (int)fminf(fmaxf(__fdiv_rn(b.z, t.stride), -kClampF), kClampF);
-                    const int cy1 = (int)fminf(fmaxf(__fdiv_rn(b.w, t.stride), -kClampF), kClampF);
-                    const int rc = min(max(t.radius, 0), 1 << 30);
-                    ghit = cx0 - rc < t.tx1 && cx1 + rc >= t.tx0 && cy0 - rc < t.ty1 && cy1 + rc >= t.ty0;
-                }
+            if (b.x <= b.z) {  // not empty (a group of NaN points keeps xmin = +inf)
+                const int cx0 = (int)fminf(fmaxf(__fdiv_rn(b.x, t.stride), -kClampF), kClampF);
+                const int cy0 = (int)fminf(fmaxf(__fdiv_rn(b.y, t.stride), -kClampF), kClampF);
+                const int cx1 = (int)fminf(fmaxf(__fdiv_rn(b.z, t.stride), -kClampF), kClampF);
+                const int cy1 = (int)fminf(fmaxf(__fdiv_rn(b.w, t.stride), -kClampF), kClampF);
+                const int rc = min(max(t.radius, 0), 1 << 30);
+                ghit = cx0 - rc < t.tx1 && cx1 + rc >= t.tx0 && cy0 - rc < t.ty1 && cy1 + rc >= t.ty0;
             }
             unsigned long long mg = __ballot(ghit);
+            if (mg == 0) continue;
             if constexpr (NW > 1) {  // every wave found the same groups; this one walks the (k * NW + wave)-th of them
+                prepare_tile();      // uniform over the workgroup: all waves see the same mg here
                 unsigned long long mine = 0;
                 int k = 0;
                 for (unsigned long long rest = mg; rest; rest &= rest - 1, ++k)
@@ -574,13 +610,21 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
             }
         }
     } else {
+        static_assert(SRC == 2 || NW == 1, "the candidate-level cull prepares the tile per wave");
         // long object lists are the normal case here (10^3 lane samples per plane) and the wave needs few registers,
         // so the candidate loads of kFetch rounds are issued together: one memory round trip per kFetch * 64 candidates
         constexpr int kFetch = 4;
-        for (int base = 0; base < t.n; base += kFetch * kCand) {
-            Cand cand[kFetch];
+        Cand cand[kFetch];
+        if (t.n > 0) {
 #pragma unroll
-            for (int u = 0; u < kFetch; ++u) cand[u] = cull_load<SRC>(t, base + u * kCand, lane);
+            for (int u = 0; u < kFetch; ++u) cand[u] = cull_load<SRC>(t, u * kCand, lane);   // BEFORE the zero stores
+        }
+        store_zeros();
+        for (int base = 0; base < t.n; base += kFetch * kCand) {
+            if (base > 0) {
+#pragma unroll
+                for (int u = 0; u < kFetch; ++u) cand[u] = cull_load<SRC>(t, base + u * kCand, lane);
+            }
 #pragma unroll
             for (int u = 0; u < kFetch; ++u) {
                 const int sub_base = base + u * kCand;
@@ -590,37 +634,34 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         }
     }
 
+    if (!tile_ready) return;   // nothing reached the tile: fused clear = the zeros above, in place = no HBM traffic at all
     if constexpr (NW > 1) {
-        if (total_hits != 0 && lane == 0) s_touched = 1;
         __syncthreads();  // all atomics of all waves landed before the tile is read back
-        if (!CLEAR && s_touched == 0) return;  // in-place: untouched tile costs no HBM traffic
     } else {
-        if (!CLEAR && total_hits == 0) return;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // all atomics landed before the tile is read back
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (col0 >= p.W) return;
-    float* plane_ptr = p.hm + (size_t)t.plane * (size_t)p.H * (size_t)p.W;
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int row = t.ty0 + row0 + i;
         if (row >= p.H) break;
         vfloat4 out = *reinterpret_cast<const vfloat4*>(&s_tile[row0 + i][(lane & 31) * 4]);
-        vfloat4* dst = reinterpret_cast<vfloat4*>(plane_ptr + (size_t)row * p.W + col0);
+        // a segment still at its initial value received nothing.  Fused clear: its zeros are already on their way
+        // (bit pattern test: a -0.0 that a negative k produced is written as before).  In place: not read, not written
+        const unsigned ibits = __float_as_uint(init);
+        if (__float_as_uint(out.x) == ibits && __float_as_uint(out.y) == ibits && __float_as_uint(out.z) == ibits &&
+            __float_as_uint(out.w) == ibits)
+            continue;
         if constexpr (!CLEAR) {
-            const vfloat4 old = *dst;
+            const vfloat4 old = *reinterpret_cast<const vfloat4*>(plane_ptr + (size_t)row * p.W + col0);
             const float nanv = __builtin_nanf("");
             out.x = max_skip_nan(old.x, out.x == init ? nanv : out.x);
             out.y = max_skip_nan(old.y, out.y == init ? nanv : out.y);
             out.z = max_skip_nan(old.z, out.z == init ? nanv : out.z);
             out.w = max_skip_nan(old.w, out.w == init ? nanv : out.w);
         }
-        if constexpr (SM >= 2) {
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(out, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, 18);
-        } else {
-            *dst = out;
-        }
+        store_segment(row, out);
     }
 }
 
@@ -971,7 +1012,10 @@ int dispatch_splat(SplatParams p, long long planes, bool clear, unsigned flags, 
     if (!p.labels) p.labels = p.radii;  // branch-free candidate loads: always a readable array (ignored when cls < 0)
     if (!vec4) return launch_splat<1, 8>(p, planes, clear, 0, stream, ev);
     const int small = accv::tune_get("hm_small", -1);   // point-like objects: the caller's ACCV_HM_SMALL_RADII hint
-    if (small > 0 || (small < 0 && small_hint)) return launch_splat_small(p, planes, clear, nt, stream, ev);
+    // the small-splat kernel has no per-plane density choice: point-like objects are the sparse case, where write-through
+    // costs up to 27 %, so the adaptive default (5) means PLAIN stores there; only an explicit
+    // ACCV_HM_WRITE_THROUGH selects SM = 4
+    if (small > 0 || (small < 0 && small_hint)) return launch_splat_small(p, planes, clear, nt == 5 ? 0 : nt, stream, ev);
     if (rows == 16) return launch_splat<4, 16>(p, planes, clear, nt, stream, ev);
 #ifdef ACCV_TUNE_BUILD
     if (accv::tune_get("hm_wpg", kWavesPerGroup) == 4) return launch_splat<4, 8, 4>(p, planes, clear, nt, stream, ev);
@@ -1282,6 +1326,7 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
     bool heavy = false;
     for (int i = 0; i < used; ++i)
         heavy = heavy || (double)batch * num_points >= 24.0 * (double)mp.scale[i].n_tiles;
+    if (const int nw = accv::tune_get("pts_nw", -1); nw > 0) heavy = nw == 4;   // A/B build only
     const dim3 grid((unsigned)tiles), block(heavy ? 256 : 64);
 #define ACCV_LAUNCH_POINTS(CL, SMV)                                                                       \
     do {                                                                                                  \

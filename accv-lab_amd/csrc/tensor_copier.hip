@@ -14,6 +14,7 @@
 //                        :775-820) so that ONE hipMemcpyAsync moves them.
 // No torch types; the python host (accvlab/multi_tensor_copier) owns tensors, streams and events.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
 
 #include <algorithm>
 #include <atomic>
@@ -47,15 +48,52 @@ inline int bucket_of(int64_t required_align)  // 16, 8, 4, 2, 1 -> 0..4 (rounded
     return 4;
 }
 
+// Process-wide singletons live on the heap and are never destroyed: a function-local static's destructor would join its
+// threads at process exit, after the HIP runtime may already be gone, and a forked child must be able to start
+// over — the parent's threads do not exist there and a mutex another thread held at fork() time stays locked for ever, so
+// the pthread_atfork child handler below simply forgets the parent's instances (leaked; fresh ones are created on demand).
+// accv_mtc_shutdown() is the orderly end: python calls it from atexit, i.e. before HIP teardown.
+template <class T>
+struct Leaked {
+    std::atomic<T*> ptr{nullptr};
+    T& get()
+    {
+        T* p = ptr.load(std::memory_order_acquire);
+        if (!p) {
+            T* fresh = new T;
+            if (ptr.compare_exchange_strong(p, fresh, std::memory_order_acq_rel))
+                p = fresh;
+            else
+                delete fresh;   // lost the race: another thread installed its instance first
+        }
+        return *p;
+    }
+    void forget() { ptr.store(nullptr, std::memory_order_release); }
+};
+void register_fork_handler();
+
 // ------------------------------------------------------------------------------------------ worker pool
 class WorkerPool {
 public:
+    static Leaked<WorkerPool>& slot()
+    {
+        static Leaked<WorkerPool> s;
+        return s;
+    }
     static WorkerPool& instance()
     {
-        static WorkerPool pool;
-        return pool;
+        register_fork_handler();
+        return slot().get();
     }
     int size() const { return (int)workers_.size(); }
+    struct Job {
+        const std::function<void(int)>* fn;
+        int tasks;
+        std::atomic<int> next{0};
+        std::atomic<int> finished{0};
+        std::mutex done_mutex;
+        std::condition_variable done_cv;
+    };
 
     // runs fn(t) for t in [0, tasks) on the pool (the calling thread helps) and waits for completion
     void parallel(int tasks, const std::function<void(int)>& fn)
@@ -80,16 +118,6 @@ public:
         queue_.erase(std::remove(queue_.begin(), queue_.end(), job), queue_.end());
     }
 
-private:
-    struct Job {
-        const std::function<void(int)>* fn;
-        int tasks;
-        std::atomic<int> next{0};
-        std::atomic<int> finished{0};
-        std::mutex done_mutex;
-        std::condition_variable done_cv;
-    };
-
     WorkerPool()
     {
         unsigned hw = std::thread::hardware_concurrency();
@@ -105,6 +133,8 @@ private:
         cv_.notify_all();
         for (auto& w : workers_) w.join();
     }
+
+private:
     static void run(Job& job)
     {
         for (;;) {
@@ -150,10 +180,15 @@ private:
 // ------------------------------------------------------------------------------------------ pinned arena
 class PinnedArena {
 public:
+    static Leaked<PinnedArena>& slot()
+    {
+        static Leaked<PinnedArena> s;
+        return s;
+    }
     static PinnedArena& instance()
     {
-        static PinnedArena a;
-        return a;
+        register_fork_handler();
+        return slot().get();
     }
     void* acquire(size_t bytes)
     {
@@ -255,25 +290,43 @@ struct AsyncStage {
     bool done = false;
     int status = 0;
     char error[512] = {0};
+    void release_arguments()
+    {
+        for (auto* v : {&nbytes, &offset, &order, &item_begin, &chunk_bytes}) std::vector<long long>().swap(*v);
+        std::vector<const void*>().swap(src);
+        std::vector<void*>().swap(staging);
+        std::vector<void*>().swap(device);
+    }
 };
 
-// ONE persistent thread executes the queued jobs in order (a job already fans its memcpy out over the worker pool);
-// tickets stay valid until waited for once.
+// ONE persistent thread executes the queued jobs in order (a job already fans its memcpy out over the worker pool).
+// A ticket stays valid until it was waited for once; tickets that are never waited for (a handle that failed before its
+// wait, or was only polled) do not pile up: a finished job drops its argument vectors at once, and submit() forgets finished
+// tickets that are more than kKeepTickets submissions old.
 class Orchestrator {
 public:
+    static constexpr long long kKeepTickets = 1024;
+    static Leaked<Orchestrator>& slot()
+    {
+        static Leaked<Orchestrator> s;
+        return s;
+    }
     static Orchestrator& instance()
     {
-        static Orchestrator o;
-        return o;
+        register_fork_handler();
+        return slot().get();
     }
     long long submit(const std::shared_ptr<AsyncStage>& job)
     {
         std::lock_guard<std::mutex> lock(mutex_);
+        if (stop_) return -1;   // after accv_mtc_shutdown
         if (!started_) {
             started_ = true;
             thread_ = std::thread([this] { loop(); });
         }
         const long long id = ++next_id_;
+        for (auto it = jobs_.begin(); it != jobs_.end() && it->first <= id - kKeepTickets;)
+            it = it->second->done ? jobs_.erase(it) : std::next(it);
         jobs_[id] = job;
         queue_.push_back(job);
         cv_.notify_all();
@@ -288,13 +341,17 @@ public:
         std::shared_ptr<AsyncStage> job = it->second;
         if (!block) return job->done ? 1 : 0;
         done_cv_.wait(lock, [&] { return job->done; });
-        jobs_.erase(it);
+        jobs_.erase(ticket);   // (the iterator may be stale: submit() can have swept older tickets meanwhile)
         if (job->status != ACCV_OK) snprintf(accv::error_buffer(), 512, "%s", job->error);
         return job->status;
     }
-
-private:
-    ~Orchestrator()
+    size_t tickets_held()
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        return jobs_.size();
+    }
+    // drain the queue, stop and join the thread (idempotent); later submissions are refused
+    void shutdown()
     {
         {
             std::lock_guard<std::mutex> lock(mutex_);
@@ -303,6 +360,10 @@ private:
         cv_.notify_all();
         if (thread_.joinable()) thread_.join();
     }
+    Orchestrator() = default;
+    ~Orchestrator() { shutdown(); }
+
+private:
     void loop()
     {
         int current_device = -1;
@@ -311,12 +372,12 @@ private:
             {
                 std::unique_lock<std::mutex> lock(mutex_);
                 cv_.wait(lock, [&] { return stop_ || !queue_.empty(); });
-                if (stop_) return;
+                if (queue_.empty()) return;   // stop requested and nothing left to run (queued jobs are drained first)
                 job = queue_.front();
                 queue_.erase(queue_.begin());
             }
             int rc = ACCV_OK;
-            if (job->device_index != current_device) {
+            if (job->device_index >= 0 && job->device_index != current_device) {   // < 0: staging only, no device involved
                 if (hipSetDevice(job->device_index) != hipSuccess) {
                     (void)hipGetLastError();
                     rc = accv::fail(ACCV_ELAUNCH, "mtc async: hipSetDevice(%d) failed", job->device_index);
@@ -332,6 +393,7 @@ private:
                 std::lock_guard<std::mutex> lock(mutex_);
                 job->status = rc;
                 if (rc != ACCV_OK) snprintf(job->error, sizeof job->error, "%s", accv::error_buffer());   // this thread's message
+                job->release_arguments();   // a ticket nobody waits for keeps ~600 bytes, not the copied argument vectors
                 job->done = true;
             }
             done_cv_.notify_all();
@@ -345,6 +407,18 @@ private:
     long long next_id_ = 0;
     bool started_ = false, stop_ = false;
 };
+
+void forget_singletons_in_child()
+{
+    WorkerPool::slot().forget();
+    PinnedArena::slot().forget();   // the parent's pinned blocks are not this process's to hand out
+    Orchestrator::slot().forget();
+}
+void register_fork_handler()
+{
+    static std::atomic<bool> done{false};
+    if (!done.exchange(true)) pthread_atfork(nullptr, nullptr, forget_singletons_in_child);
+}
 
 }  // namespace
 
@@ -507,11 +581,25 @@ int accv_mtc_stage_h2d_async(long long n_items, const void* const* src, const lo
     job->stream = stream;
     job->threads = threads;
     job->device_index = device_index;
-    *ticket_out = Orchestrator::instance().submit(job);
+    const long long ticket = Orchestrator::instance().submit(job);
+    if (ticket < 0) return accv::fail(ACCV_ERUNTIME, "mtc_stage_h2d_async: the orchestration thread was shut down");
+    *ticket_out = ticket;
     return ACCV_OK;
 }
 
 int accv_mtc_async_wait(long long ticket) { return Orchestrator::instance().wait(ticket, true); }
+
+/* Orderly end of the native orchestration thread: runs what is still queued, then stops and joins the thread; later
+ * accv_mtc_stage_h2d_async calls fail.  The python package registers it with atexit so that no job is inside
+ * hipMemcpyAsync while the HIP runtime is torn down (the reference's CopyThreadPool joins its workers in its destructor,
+ * multi_tensor_copier.cpp:300-312).  Idempotent. */
+void accv_mtc_shutdown(void)
+{
+    if (Orchestrator* o = Orchestrator::slot().ptr.load(std::memory_order_acquire)) o->shutdown();
+}
+
+/* Tickets the orchestrator still remembers (diagnostics / tests: bounded even when handles are never waited for). */
+long long accv_mtc_async_tickets_held(void) { return (long long)Orchestrator::instance().tickets_held(); }
 
 /* 1 = the job has finished (successfully or not; its status is what accv_mtc_async_wait returns), 0 = still running,
  * negative = unknown ticket. */

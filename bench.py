@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): heat-map frames/s + achieved HBM GB/s, 1920x1080 fp32, ragged
 N_obj in [1,128] packed by batching_helpers, batch 64 per GPU (configs[1]); frames shard across ranks with
-no data-path collective (weak scaling: every rank draws its own 64-frame batch).
+no data-path collective.  Two scaling modes, both built from accvlab.draw_heatmap.sharding:
+  weak   (default, `value`): every rank draws its OWN 64-frame batch (seed 42 + rank) — per-GPU work is fixed;
+  strong (`--scaling strong`, and `secondary.strong_scaling` of every weak run): the ONE 64-frame batch of seed 42 is cut with
+         `shard_range` into 64 / 32 / 16 / 8 frames per GPU at 1 / 2 / 4 / 8 GPUs.
 
 One "step" = one fused clear+draw of the whole batch through the public operator
 ``accvlab.draw_heatmap.draw_heatmap_batched(..., clear=True)`` -> C-ABI -> one HIP kernel launch, with the
@@ -40,7 +43,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 # 256 CUs x 4 SIMDs x 64 lanes / 8 cycles x 2.4 GHz
 EXP_PEAK_PER_S = 256 * 4 * 64 / 8 * 2.4e9
 H, W = 1080, 1920
-TRAFFIC_PROFILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_PROFILES = [os.path.join("profiles", f) for f in ("r03_traffic.json", "r02_traffic.json")]   # newest first
+STRONG_TOTAL = 64   # frames of the C4 batch that the strong mode cuts over the ranks
 
 
 def cpu_baseline(centers_l, radii_l, batch):
@@ -166,18 +170,26 @@ def device_env(dev_index):
     return env
 
 
-def committed_traffic(kernel: str):
-    """HBM bytes per launch from the committed PMC profile — only if it was taken on the SAME kernel instantiation as
-    the one timed now (the file names it); otherwise (None, reason)."""
-    path = os.path.join(ROOT, TRAFFIC_PROFILE)
-    try:
-        rec = json.load(open(path))
-    except Exception:  # noqa: BLE001
-        return None, f"{TRAFFIC_PROFILE} not present"
+def committed_traffic(kernel: str, frames: int):
+    """HBM bytes per launch from the newest committed PMC profile that was taken on the SAME kernel instantiation as the one
+    timed now (the file names it); otherwise (None, reason)."""
     want = kernel.split(" grid")[0]
-    if rec.get("kernel") != want:
-        return None, f"{TRAFFIC_PROFILE} was taken on {rec.get('kernel')!r}, this run dispatched {want!r}"
-    return rec.get("hbm_bytes_per_launch"), f"{TRAFFIC_PROFILE} (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, commit {rec.get('commit')})"
+    reasons = []
+    for rel in TRAFFIC_PROFILES:
+        try:
+            rec = json.load(open(os.path.join(ROOT, rel)))
+        except Exception:  # noqa: BLE001
+            reasons.append(f"{rel} not present")
+            continue
+        if rec.get("kernel") != want:
+            reasons.append(f"{rel} was taken on {rec.get('kernel')!r}, this run dispatched {want!r}")
+            continue
+        if int(rec.get("frames", 64)) != frames:
+            reasons.append(f"{rel} was taken on {rec.get('frames', 64)} frames per launch, this run draws {frames}")
+            continue
+        return rec.get("hbm_bytes_per_launch"), (f"{rel} (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, commit "
+                                                 f"{rec.get('commit')}); not measured in this run")
+    return None, "; ".join(reasons)
 
 
 def per_launch_kernel_ms(nat, step, steps, sync):
@@ -226,6 +238,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU")
     ap.add_argument("--rule", default="A", choices=["A", "B"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="which mode `value` reports; the other one is carried in `secondary`")
+    ap.add_argument("--no-configs", action="store_true", help="skip configs[0] / [2] / [3] (secondary.configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the rule-B / in-place / zero-fill side measurements")
     args = ap.parse_args()
@@ -314,6 +329,30 @@ def main():
     kern_ms = sharding.max_over_ranks(kern_ms, device=red_dev)
     region_ms = sharding.max_over_ranks(region_ms, device=red_dev)
 
+    # ---- strong scaling (every rank, same collectives in the same order): the 64 frames of seed 42, cut over the ranks
+    def strong_inputs(begin, end, all_lists=[]):
+        if not all_lists:
+            all_lists.extend(wl.heatmap_objects(STRONG_TOTAL, H, W, 1, 128, args.rule, seed=42))
+        cl, rl = all_lists[0][begin:end], all_lists[1][begin:end]
+        c = combine_data(cl, device=dev)
+        r = combine_data(rl, device=dev, other_with_same_sample_sizes=c)
+        return c, r, int(sum(int(x.shape[0]) for x in rl))
+
+    strong_buf = []
+
+    def strong_step(begin, end):
+        c, r, _ = strong_inputs(begin, end)
+        if hm.shape[0] < end - begin and (not strong_buf or strong_buf[0].shape[0] < end - begin):
+            strong_buf[:] = [torch.empty((end - begin, H, W), dtype=torch.float32, device=dev)]   # --batch below the shard size
+        view = (hm if hm.shape[0] >= end - begin else strong_buf[0])[: end - begin]
+        return lambda: draw_heatmap_batched(view, c, r, 6.0, 1.0, clear=True)
+
+    strong = None
+    if world > 1 or args.scaling == "strong":
+        strong = sharding.strong_scaling_run(strong_step, STRONG_TOTAL, rank, world, args.steps, args.warmup + 300,
+                                             dist=dist, sync=sync, device=red_dev)
+        strong["kernel"] = nat.last_dispatch()
+
     # secondary, rank 0 only: rule B, the reference's exact in-place semantics, and the streaming-write ceiling
     extra = {}
     if rank == 0 and not args.no_secondary:
@@ -362,6 +401,41 @@ def main():
                         "achieved_GBps": b_in_bytes / ms_b_in / 1e6},
             "clipped_area_sum_per_frame": wc_b["clipped_area_sum_per_frame"], "tiles_touched": wc_b["tiles_touched"]}
 
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # what a shard of the strong split costs on ONE GPU (all shards of each split, slowest one counts): predicts the
+        # strong curve the driver measures — an 8-frame launch is 66 MB of map, i.e. store stream + launch boundary
+        def shard_ms(begin, end, iters=200, warm=100):
+            fn = strong_step(begin, end)
+            for _ in range(warm):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            sync()
+            return a.elapsed_time(b) / iters
+
+        pred = {}
+        for n in (1, 2, 4, 8):
+            per = [shard_ms(*sharding.shard_range(STRONG_TOTAL, r, n)) for r in range(n)]
+            frames = sharding.shard_range(STRONG_TOTAL, 0, n)[1]
+            pred[str(n)] = {"frames_per_gpu": frames, "ms_slowest_shard": max(per), "ms_fastest_shard": min(per),
+                            "predicted_frames_per_s": STRONG_TOTAL / max(per) * 1e3,
+                            "frac_of_hbm_peak_slowest_shard": frames * H * W * 4 / max(per) / 1e6 / HBM_PEAK_GBPS}
+        base = pred["1"]["predicted_frames_per_s"]
+        for n in pred:
+            pred[n]["predicted_speedup"] = pred[n]["predicted_frames_per_s"] / base
+        extra["strong_scaling_prediction_from_one_gpu"] = {
+            "splits": pred, "note": "each shard of the seed-42 64-frame batch drawn back to back on this GPU (HIP events, 200 "
+                                    "launches); N ranks run their shards concurrently, so the job takes the slowest shard's time"}
+    if rank == 0 and world == 1 and not args.no_secondary and not args.no_configs:
+        import bench_configs
+
+        t_cfg = time.perf_counter()
+        extra["configs"] = bench_configs.run()
+        extra["configs_wall_s"] = time.perf_counter() - t_cfg
+
     if rank != 0:
         if dist is not None:
             dist.barrier()          # wait for rank 0's secondary measurements, then leave together
@@ -370,7 +444,7 @@ def main():
 
     alg_bytes = B * H * W * 4 + 12 * n_objects + 4 * B  # H*W*4 + 12*N_i + 4 per frame
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic, traffic_source = committed_traffic(kernel)
+    traffic, traffic_source = committed_traffic(kernel, B)
     tile_h = 32 if "R=16" in kernel else 16
     wc = work_counters(centers_l, radii_l, 128, tile_h)
     # exp evaluations of the tile kernel: per (tile, hit) one row-factor table entry per tile row + 4 column factors per lane
@@ -378,25 +452,42 @@ def main():
     wc["exp_evaluations_per_launch"] = exps
     wc["transcendental_ceiling"] = {"peak_exp_per_s": EXP_PEAK_PER_S, "min_ms_per_launch": exps / EXP_PEAK_PER_S * 1e3,
                                     "fraction_of_kernel_time": exps / EXP_PEAK_PER_S * 1e3 / kern_ms}
+    weak = {"frames_per_s": sharding.job_throughput(B, world, wall_ms), "ms_per_step": wall_ms, "frames_per_rank": B,
+            "total_frames": B * world}
+    if strong is not None:
+        extra["strong_scaling"] = strong
+    extra["weak_scaling"] = weak
+    use_strong = args.scaling == "strong"
     out = {
         "metric": "heatmap frames/sec (1920x1080 fp32, ragged N_obj in [1,128], fused clear+draw)",
-        "value": sharding.job_throughput(B, world, wall_ms),
+        "value": strong["frames_per_s"] if use_strong else weak["frames_per_s"],
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": wall_ms,
+        "ms_per_step": strong["ms_per_step"] if use_strong else wall_ms,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"configs[1]: draw_heatmap_batched 1920x1080, batch {B}/GPU, ragged N_obj in [1,128] "
-                               f"via batching_helpers.combine_data, radius rule {args.rule}, factor 6, k 1, fp32",
-                   "frames_per_gpu": B, "objects_per_gpu": n_objects, "parallelism": f"frame-sharded x{world}",
-                   "seed": seed},
+        "config": ({"workload": f"configs[4] strong split of configs[1]: ONE {STRONG_TOTAL}-frame batch (seed 42) of draw_heatmap_batched "
+                                f"1920x1080, ragged N_obj in [1,128], radius rule {args.rule}, cut contiguously over {world} GPU(s) "
+                                f"({strong['frames_per_rank']} frames per rank), fp32",
+                    "frames_per_gpu": strong["frames_per_rank"], "parallelism": f"frame-sharded x{world} (strong)", "seed": 42}
+                   if use_strong else
+                   {"workload": f"configs[1]: draw_heatmap_batched 1920x1080, batch {B}/GPU, ragged N_obj in [1,128] "
+                                f"via batching_helpers.combine_data, radius rule {args.rule}, factor 6, k 1, fp32",
+                    "frames_per_gpu": B, "objects_per_gpu": n_objects, "parallelism": f"frame-sharded x{world}",
+                    "seed": seed}),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     # the same bytes over (e1 - e0) / K of the timed region and over the barrier-bracketed wall time of `value`
+                     "frac_region": alg_bytes / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "frac_wall": alg_bytes / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "frac_definition": "frac = back-to-back launches (kernel_ms); frac_region = (e1 - e0) / K incl. the start-up "
+                                        "of launch 1 after the opening barrier; frac_wall = host wall clock of the weak timed region",
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": kernel, "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
                      "kernel_ms_source": "HIP events on the launch stream inside the timed region: end of launch 1 -> end of "
                                          "launch K, divided by K - 1 (back-to-back launches)",

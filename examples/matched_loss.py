@@ -86,6 +86,29 @@ def loss_batched(gt_boxes, gt_labels, gt_weights, pred_boxes, pred_scores, pred_
     return cls_loss + box_loss + exist_loss
 
 
+def loss_batched_fused(gt_boxes, gt_labels, gt_weights, pred_boxes, pred_scores, pred_exist, match_gt, match_pred):
+    """The same loss with the class and box terms through ``bh.matched_pair_loss_sum`` (one launch each: the matched
+    gathers, the per-object loss — L1 against one-hot labels / 1 - IoU, the two losses of the reference example — the
+    weight look-up and the masked per-frame sum).  The existence term keeps the operator composition: it needs the
+    PER-OBJECT overlaps, not their sum."""
+    num_q = pred_scores.shape[1]
+    cls_loss = bh.matched_pair_loss_sum(gt_labels, pred_scores, match_gt, match_pred, gt_weights, kind="onehot_l1")
+    box_loss = bh.matched_pair_loss_sum(gt_boxes, pred_boxes, match_gt, match_pred, gt_weights, kind="iou_xyxy", eps=EPS)
+
+    box_g = bh.batched_indexing_access(gt_boxes, match_gt)
+    w = bh.batched_indexing_access(gt_weights, match_gt)
+    box_p = bh.batched_indexing_access(pred_boxes, match_pred)
+    box_term = w.tensor * (1.0 - _iou(box_g.tensor, box_p.tensor))
+    matched = bh.get_mask_from_indices(num_q, match_pred)
+    w_match = w.create_with_sample_sizes_like_self(w.tensor * (1.0 - box_term), non_uniform_dim=1)
+    n = w_match.sample_sizes
+    balance = torch.nan_to_num(n / (num_q - n), 0.0)
+    background = (bh.average_over_targets(w_match) * balance).unsqueeze(-1).repeat(1, num_q)
+    w_all = bh.batched_indexing_write(w_match, match_pred, background)
+    exist_loss = (w_all * (pred_exist - matched.to(torch.float32)).abs()).sum(1)
+    return cls_loss + box_loss + exist_loss
+
+
 # ------------------------------------------------------------------------------------------------ per-sample loop
 def loss_per_sample(gt_boxes_l, gt_labels_l, gt_weights_l, pred_boxes, pred_scores, pred_exist):
     """The same computation frame by frame with plain tensor indexing (what the batched form replaces)."""
@@ -129,9 +152,10 @@ def make_inputs(batch, num_queries, num_classes, max_gt, device, seed=0, min_gt=
     return gt_boxes_l, gt_labels_l, gt_weights_l, pred_boxes, pred_scores, pred_exist
 
 
-def run_batched(gt_boxes_l, gt_labels_l, gt_weights_l, pred_boxes, pred_scores, pred_exist):
+def run_batched(gt_boxes_l, gt_labels_l, gt_weights_l, pred_boxes, pred_scores, pred_exist, fused=False):
     gt_boxes = bh.combine_data(gt_boxes_l)
     gt_labels = bh.combine_data(gt_labels_l, other_with_same_sample_sizes=gt_boxes)
     gt_weights = bh.combine_data(gt_weights_l, other_with_same_sample_sizes=gt_boxes)
     m_gt, m_pred = match_batched(gt_boxes, gt_labels, pred_boxes, pred_scores)
-    return loss_batched(gt_boxes, gt_labels, gt_weights, pred_boxes, pred_scores, pred_exist, m_gt, m_pred)
+    fn = loss_batched_fused if fused else loss_batched          # the fused op is GPU-only
+    return fn(gt_boxes, gt_labels, gt_weights, pred_boxes, pred_scores, pred_exist, m_gt, m_pred)

@@ -225,6 +225,29 @@ int accv_matched_pair_reduce_bwd_f32(const float* a, const float* b, const void*
                                      int counts_i64, float* grad_a_or_null, float* grad_b_or_null,
                                      float* grad_w_or_null, void* stream);
 
+/* Round 3: the same two launches for every dtype the replaced gathers accept and for the reference example's own per-object
+ * losses.  dtype: 0 f32, 1 f16, 2 bf16, 3 f64 — of a, b and weights; arithmetic, `out` and the gradient buffers are f32 (f64 for
+ * f64 data).  kind 0-2 as above, plus
+ *   3 = 1 - IoU of (x0, y0, x1, y1) boxes (row_elems == 4) with negative intersection extents clamped to 0 and the union
+ *       clamped to `eps`: _per_object_bbox_overlap_loss, packages/batching_helpers/example/loss_computation.py:240-274;
+ *       the backward follows torch's autograd of that code (clamps pass no gradient, max / min ties split it evenly);
+ *   4 = L1 between one-hot class labels and scores: `a` holds INTEGER labels [batch, w_a] (int32, or int64 with
+ *       ACCV_MP_LABELS_I64), b the scores [batch, w_b, row_elems]; sum_c |[c == label] - b[..., c]|
+ *       (loss_computation.py:37-43 class branch, :225-238); a label outside [0, row_elems) matches no class.
+ * flags: ACCV_MP_IDX_I64 / ACCV_MP_COUNTS_I64 / ACCV_MP_LABELS_I64. */
+#define ACCV_MP_IDX_I64 1u
+#define ACCV_MP_COUNTS_I64 2u
+#define ACCV_MP_LABELS_I64 4u
+int accv_matched_pair_reduce(const void* a, const void* b, const void* idx_a, const void* idx_b, const void* counts,
+                             const void* weights_or_null, long long batch, long long w_a, long long w_b, long long w_idx,
+                             long long idx_stride, long long row_elems, int kind, int dtype, float beta, float eps,
+                             unsigned flags, void* out, void* stream);
+int accv_matched_pair_reduce_bwd(const void* a, const void* b, const void* idx_a, const void* idx_b, const void* counts,
+                                 const void* weights_or_null, const void* grad_out, long long batch, long long w_a,
+                                 long long w_b, long long w_idx, long long idx_stride, long long row_elems, int kind,
+                                 int dtype, float beta, float eps, unsigned flags, void* grad_a_or_null,
+                                 void* grad_b_or_null, void* grad_w_or_null, void* stream);
+
 /* combine_data / split on device (batched_processing_py.py:410-423, ragged_batch.py:870-934):
  * unpack == 0: padded[i, j, :] = flat[offsets[i] + j, :] for j < sizes[i], zero bytes elsewhere;
  * unpack != 0: the inverse copy (flat <- padded, valid entries only).  offsets/sizes are device int64. */
@@ -275,13 +298,22 @@ int accv_mtc_stage_h2d(long long n_items, const void* const* src, const long lon
  * the job is queued and `*ticket_out` returned at once; no Python and no interpreter lock are involved in the work.
  * accv_mtc_async_wait(ticket) blocks until every transfer of the job has been ENQUEUED on `stream` (completion is the
  * caller's stream event) and returns the job's status; accv_mtc_async_poll(ticket) is 1 when it has finished, else 0.
- * A ticket is forgotten by the wait that returns its status. */
+ * A ticket is forgotten by the wait that returns its status.  device_index < 0 selects no device (a staging-only job whose
+ * device[] entries are all NULL). */
 int accv_mtc_stage_h2d_async(long long n_items, const void* const* src, const long long* nbytes, const long long* offset,
                              const long long* order, long long n_chunks, const long long* item_begin,
                              void* const* staging, void* const* device, const long long* chunk_bytes, void* stream,
                              int threads, int device_index, long long* ticket_out);
 int accv_mtc_async_wait(long long ticket);
 int accv_mtc_async_poll(long long ticket);
+/* Orderly end of that thread (counterpart of ~CopyThreadPool joining its workers, multi_tensor_copier.cpp:300-312): runs
+ * what is still queued, stops and joins; later accv_mtc_stage_h2d_async calls fail with ACCV_ERUNTIME.  Idempotent.  The
+ * python package calls it from atexit, i.e. before the HIP runtime is torn down.  A forked child starts with fresh
+ * (empty) pool / arena / orchestrator state: the parent's threads do not exist there. */
+void accv_mtc_shutdown(void);
+/* Number of tickets the orchestrator still remembers.  Bounded: a ticket is forgotten by the wait that returns its
+ * status, and finished tickets nobody waited for are dropped once 1024 later jobs were submitted. */
+long long accv_mtc_async_tickets_held(void);
 
 /* One kernel that gathers (scatter == 0) many small device tensors into `packed`, or fans `packed` out again
  * (scatter != 0).  items: array of {const void* ptr; long long offset_in_packed; long long nbytes;} readable by

@@ -1,189 +1,16 @@
 #!/usr/bin/env python3
-"""The secondary BASELINE.json configs in the SAME line format as bench.py (one JSON object per config: metric, value,
-unit, ms_per_step, roofline, cpu_baseline, config.workload), so that they can be read next to the headline line:
-
-  configs[0]  batching_helpers pack -> mask -> split on torch-CPU, 64 samples, N in [1,32], (n,4) fp32
-  configs[2]  multi_tensor_copier: 10k mixed fp32/int64 small CPU tensors -> GPU (background and inline), vs naive .to()
-  configs[3]  multi-scale heat-maps (strides 4/8/16 of 3840x2160, batch 32) + lane raster, from float boxes / polylines
-
-configs[1] is bench.py itself; configs[4] is bench.py under torch.distributed.run.  `roofline.bound` names what limits
-the config: "host" (call overhead; <= 32 KB move), "pcie" (host link), "hbm".  The CPU baselines are the reference-style
-formulations run on this host (kind "port": this repo's restatement, the reference's files do not travel).
-"""
-from __future__ import annotations
-
+"""Prints the secondary BASELINE configs (configs[0] / [2] / [3]) as bench-format JSON lines of their own:
+`python3 scripts/bench_configs.py [0] [2] [3]`.  The measurement code lives in bench_configs.py at the repo root (bench.py
+carries the same objects in `secondary.configs`); this entry point is what the rocprofv3 summaries under profiles/ were
+taken on (`rocprofv3 --kernel-trace --stats -- python3 scripts/bench_configs.py 3`)."""
 import json
 import os
 import sys
-import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "accv-lab_amd")]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-import bench_workloads as wl  # noqa: E402
-
-PCIE_GBPS = 63.0     # PCIe Gen5 x16 (MI355X_MICROARCH.md, chip-level parameters)
-HBM_GBPS = 8000.0
-
-
-def _timeit(fn, warm, iters, sync=None):
-    for _ in range(warm):
-        fn()
-    if sync:
-        sync()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        fn()
-    if sync:
-        sync()
-    return (time.perf_counter() - t0) / iters
-
-
-def _line(**kw):
-    base = {"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
-    base.update(kw)
-    print(json.dumps(base), flush=True)
-
-
-def config0():
-    from accvlab.batching_helpers import combine_data
-
-    boxes = wl.ragged_boxes(64, 1, 32, seed=0)
-
-    def ours():
-        rb = combine_data(boxes)
-        _ = rb.mask
-        return rb.split()
-
-    def reference_style():   # one slice-assign per sample, per-sample size read (batched_processing_py.py:410-427)
-        n = max(b.shape[0] for b in boxes)
-        data = torch.zeros((len(boxes), n, 4))
-        sizes = torch.empty(len(boxes), dtype=torch.int64)
-        for i, b in enumerate(boxes):
-            sizes[i] = b.shape[0]
-            data[i, : b.shape[0]] = b
-        mask = torch.arange(n).unsqueeze(0) < sizes.unsqueeze(1)
-        return [data[i][: sizes[i]] for i in range(len(boxes))], mask
-
-    t, tl = _timeit(ours, 50, 500), _timeit(reference_style, 20, 200)
-    nbytes = sum(b.numel() * 4 for b in boxes) * 2
-    _line(metric="ragged pack + mask + split on torch-CPU (ops/s)", value=1.0 / t, unit="ops/s", steps=500, warmup=50,
-          ms_per_step=t * 1e3, dtype="f32",
-          config={"workload": "configs[0]: batching_helpers combine_data -> .mask -> .split(), 64 CPU samples (n,4) fp32, n in [1,32]"},
-          roofline={"bound": "host", "achieved": nbytes / t / 1e9, "peak": None, "unit": "GB/s", "frac": None, "traffic": None,
-                    "note": f"{nbytes} bytes moved per op: call-overhead bound, no memory roofline applies"},
-          cpu_baseline={"value": 1.0 / tl, "unit": "ops/s", "cores": 1, "kind": "port",
-                        "sample": "the reference's python structure (one slice-assign per sample, per-sample size read), 200 ops"})
-
-
-def _leaves(x):
-    if isinstance(x, torch.Tensor):
-        return [x]
-    if isinstance(x, dict):
-        return [l for v in x.values() for l in _leaves(v)]
-    if isinstance(x, (list, tuple)):
-        return [l for v in x for l in _leaves(v)]
-    return []
-
-
-def config2(n=10_000):
-    from accvlab.multi_tensor_copier import start_copy
-
-    dev = torch.device("cuda", 0)
-    tree = wl.meta_tensor_tree(n, seed=0)
-    leaves = _leaves(tree)
-    nbytes = sum(t.numel() * t.element_size() for t in leaves)
-    sync = torch.cuda.synchronize
-    t_bg = _timeit(lambda: start_copy(tree, dev).get(), 10, 50, sync)
-    t_in = _timeit(lambda: start_copy(tree, dev, use_background_thread=False).get(), 10, 50, sync)
-    small = wl.meta_tensor_tree(528, seed=0)
-    t_bg_s = _timeit(lambda: start_copy(small, dev).get(), 20, 200, sync)
-    t_in_s = _timeit(lambda: start_copy(small, dev, use_background_thread=False).get(), 20, 200, sync)
-    # last: 50 000 tiny device allocations leave the caching allocator in a state that slows whatever is timed next
-    t_naive = _timeit(lambda: [t.to(dev) for t in leaves], 2, 5, sync)
-    _line(metric="multi_tensor_copier host->GPU copies of a 10k-leaf nested structure (copies/s)", value=1.0 / t_bg, unit="copies/s",
-          steps=50, warmup=10, ms_per_step=t_bg * 1e3, dtype="u8",
-          config={"workload": f"configs[2]: {len(leaves)} mixed fp32/int64 small CPU tensors ({nbytes} bytes) in a list of dicts of lists, "
-                              "pinned pack + async H2D, start_copy(...).get(), default use_background_thread=True"},
-          roofline={"bound": "pcie", "achieved": nbytes / t_bg / 1e9, "peak": PCIE_GBPS, "unit": "GB/s",
-                    "frac": nbytes / t_bg / 1e9 / PCIE_GBPS, "traffic": None,
-                    "note": "host-overhead bound (walk, plan, views, rebuild of 10k python objects), not link bound"},
-          secondary={"inline_ms": t_in * 1e3, "background_ms": t_bg * 1e3, "inline_528_ms": t_in_s * 1e3,
-                     "background_528_ms": t_bg_s * 1e3},
-          cpu_baseline={"value": 1.0 / t_naive, "unit": "copies/s", "cores": 1, "kind": "port",
-                        "sample": "naive per-tensor .to('cuda') over the same leaves (the baseline of the reference's evaluation.py:43-87), 5 passes"})
-
-
-def config3():
-    from accvlab.batching_helpers import combine_data
-    from accvlab.draw_heatmap import draw_heatmap_multiscale, draw_polylines_multiscale
-    from oracle import h1 as oracle
-
-    dev = torch.device("cuda", 0)
-    B, SH, SW = 32, 2160, 3840
-    strides = (4.0, 8.0, 16.0)
-    g = torch.Generator().manual_seed(7)
-    cs, bs = [], []
-    for _ in range(B):
-        n = int(torch.randint(1, 129, (1,), generator=g))
-        c = torch.rand(n, 2, generator=g) * torch.tensor([SW, SH])
-        half = torch.rand(n, 4, generator=g) * 400
-        cs.append(c)
-        bs.append(torch.cat([c - half[:, :2], c + half[:, 2:]], 1))
-    crb = combine_data(cs, device=dev)
-    brb = combine_data(bs, device=dev, other_with_same_sample_sizes=crb)
-    maps = [torch.empty((B, int(SH / s), int(SW / s)), device=dev) for s in strides]
-    lane_maps = [torch.empty_like(m) for m in maps]
-    L, P = 8, 24
-    x0 = torch.rand(B, L, 1, generator=g) * SW
-    t_ = torch.linspace(0, 1, P).view(1, 1, P)
-    xs = x0 + (torch.rand(B, L, 1, generator=g) - 0.5) * SW * 0.5 * t_ + 60 * torch.sin(6 * t_ + x0)
-    ys = SH * (1 - 0.9 * t_).expand(B, L, P)
-    lanes = torch.stack([xs, ys], -1).to(dev)
-
-    def step():
-        draw_heatmap_multiscale(maps, crb, brb, strides, 6.0, 1.0, clear=True)
-        draw_polylines_multiscale(lane_maps, lanes, 256, 2, strides, clear=True)
-
-    sync = torch.cuda.synchronize
-    t = _timeit(step, 50, 500, sync)
-    t_boxes = _timeit(lambda: draw_heatmap_multiscale(maps, crb, brb, strides, 6.0, 1.0, clear=True), 50, 500, sync)
-    nbytes = 2 * sum(m.numel() * 4 for m in maps)       # box maps + lane maps, every pixel written once
-    # CPU baseline: the oracle on the integer box targets of the three scales (one pass over the batch)
-    c_np, b_np, sizes = crb.tensor.cpu().numpy(), brb.tensor.cpu().numpy(), crb.sample_sizes.cpu().numpy()
-    threads = oracle.max_threads()
-    t0 = time.perf_counter()
-    for m, s in zip(maps, strides):
-        s32 = np.float32(s)
-        mn = np.minimum(np.minimum(c_np[..., 0] - b_np[..., 0], c_np[..., 1] - b_np[..., 1]),
-                        np.minimum(b_np[..., 2] - c_np[..., 0], b_np[..., 3] - c_np[..., 1]))
-        r = np.maximum(1, np.ceil(mn / s32)).astype(np.int32)
-        ci = np.trunc(c_np / s32).astype(np.int32)
-        hm = np.empty(tuple(m.shape), dtype=np.float32)
-        oracle.draw_heatmap_batched(hm, ci, r, sizes, clear=True, threads=threads)
-    t_cpu = time.perf_counter() - t0
-    _line(metric="multi-scale target maps + lane raster (frames/s), 3840x2160 source, strides 4/8/16", value=B / t, unit="frames/s",
-          steps=500, warmup=50, ms_per_step=t * 1e3, dtype="f32",
-          config={"workload": "configs[3]: batch 32, box maps at strides 4/8/16 from float boxes (1 launch, draw_heatmap_multiscale) + "
-                              "lane maps from 8 polylines x 24 points, 256 samples, radius 2 (2 launches, draw_polylines_multiscale)"},
-          roofline={"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_GBPS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_GBPS,
-                    "traffic": None, "algorithmic_bytes": nbytes,
-                    "note": "three launches over 87 MB of maps: launch / cull bound, far below the HBM roof by construction"},
-          secondary={"box_maps_only_ms": t_boxes * 1e3, "box_maps_only_frames_per_s": B / t_boxes},
-          cpu_baseline={"value": B / t_cpu, "unit": "frames/s", "cores": threads, "kind": "port",
-                        "sample": "box maps of the three scales through the CPU oracle (one pass over the 32-frame batch); no lane raster "
-                                  "(the reference has none)"})
-
+import bench_configs  # noqa: E402
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["0", "2", "3"]
-    if "0" in which:
-        config0()
-    if torch.cuda.is_available():
-        if "2" in which:
-            config2()
-        if "3" in which:
-            config3()
+    for line in bench_configs.run(tuple(sys.argv[1:]) or ("0", "2", "3")).values():
+        print(json.dumps(line), flush=True)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where does splat_points_multi_kernel (the lane splat of BASELINE config 3) spend its time?  Calls the C-ABI entry point
 directly on pre-sampled lanes (group boxes given) and varies: no lanes at all (empty-tile floor), the number of lanes, the
-radius, the scales."""
+radius, the scales.  `--alt-lib PATH` times a second build of the library (scripts/build_prev_lib.sh) beside the shipped one
+in the same process and checks that both write the same maps."""
 import ctypes
 import json
 import os
@@ -32,6 +33,12 @@ def gpu_us(fn, n=200):
 def main():
     dev = torch.device("cuda", 0)
     lib = nat.lib()
+    libs = {"shipped": lib}
+    if "--alt-lib" in sys.argv:
+        alt = ctypes.CDLL(os.path.abspath(sys.argv[sys.argv.index("--alt-lib") + 1]))
+        alt.accv_draw_points_multiscale_f32.restype, alt.accv_draw_points_multiscale_f32.argtypes = \
+            nat.SIGNATURES["accv_draw_points_multiscale_f32"]
+        libs["alt"] = alt
     B, SH, SW, L, P, Q = 32, 2160, 3840, 8, 24, 256
     g = torch.Generator().manual_seed(7)
     x0 = torch.rand(B, L, 1, generator=g) * SW
@@ -53,11 +60,22 @@ def main():
         ws_ = (ctypes.c_int * k)(*[m.size(2) for m in maps])
         st = (ctypes.c_float * k)(*strides)
         flags = (nat.HM_CLEAR if clear else 0) | nat.HM_GROUP_BOXES_GIVEN
-        fn = lambda: nat.check(lib.accv_draw_points_multiscale_f32(ptrs, hs, ws_, st, k, B, samples.data_ptr(), counts.data_ptr(),
-                                                                   n, radius, 6.0, 1.0, flags, work.data_ptr(), ws_bytes, stream), "points")
-        us = gpu_us(fn)
         nbytes = sum(m.numel() * 4 for m in maps)
-        return {"us": round(us, 1), "GBps": round(nbytes / us / 1e3, 1), "kernel": nat.last_dispatch()}
+        out, ref = {}, None
+        for name, handle in libs.items():
+            fn = lambda: nat.check(handle.accv_draw_points_multiscale_f32(ptrs, hs, ws_, st, k, B, samples.data_ptr(), counts.data_ptr(),
+                                                                          n, radius, 6.0, 1.0, flags, work.data_ptr(), ws_bytes, stream), "points")
+            for m in maps:
+                m.fill_(0.25)
+            us = gpu_us(fn)
+            out[name] = {"us": round(us, 1), "GBps": round(nbytes / us / 1e3, 1)}
+            snap = [m.clone() for m in maps]
+            if ref is None:
+                ref = snap
+            else:
+                out[name]["same_as_shipped"] = all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(ref, snap))
+        out["kernel"] = nat.last_dispatch()
+        return out
 
     full = torch.full((B,), n, dtype=torch.int32, device=dev)
     none = torch.zeros(B, dtype=torch.int32, device=dev)

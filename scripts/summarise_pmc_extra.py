@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Mean per-launch value of every counter of scripts/collect_pmc_extra.sh for the splat kernel, plus derived ratios."""
+"""Mean per-launch value of every counter of scripts/collect_pmc_extra.sh / collect_r03_configs.sh per kernel, plus derived
+ratios.  `summarise_pmc_extra.py DIR [name-filter ...]`: kernels whose name contains one of the filters (default: the splat
+kernel of the headline)."""
 import collections
 import csv
 import glob
@@ -8,7 +10,7 @@ import os
 import sys
 
 
-def main(out):
+def main(out, filters=("splat_kernel<",)):
     res = {}
     for sub in ("a", "b"):
         files = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)
@@ -16,12 +18,17 @@ def main(out):
             continue
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(files[0])):
-            if "splat_kernel<" in r["Kernel_Name"]:
-                agg[(r["Kernel_Name"].split("(anonymous namespace)::")[-1][:40], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if any(f in r["Kernel_Name"] for f in filters):
+                agg[(r["Kernel_Name"].split("(anonymous namespace)::")[-1][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in agg.items():
             res.setdefault(k, {})[c] = sum(v) / len(v)
+            res[k]["launches_sampled"] = len(v)
     for k, c in res.items():
         d = {}
+        if "SQ_INSTS_VMEM_RD" in c and c.get("SQ_WAVES"):
+            d["load_instructions_per_wave"] = c["SQ_INSTS_VMEM_RD"] / c["SQ_WAVES"]
+        if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAVES"):
+            d["wave_cycles_per_wave"] = c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"]
         if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c and c["SQ_WAVES"]:
             d["valu_instructions_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
             d["salu_instructions_per_wave"] = c.get("SQ_INSTS_SALU", 0) / c["SQ_WAVES"]
@@ -38,4 +45,4 @@ def main(out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], tuple(sys.argv[2:]) or ("splat_kernel<",))

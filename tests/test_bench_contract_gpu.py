@@ -47,3 +47,30 @@ def test_bench_line_has_the_contract_fields(monkeypatch):
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
     assert "inplace" in d["secondary"] and "rule_B" in d["secondary"]
+    assert r["traffic"] is None and "frames per launch" in r["traffic_source"]      # the PMC record is for 64-frame launches
+    assert r["frac_wall"] <= r["frac_region"] * 1.02 <= r["frac"] * 1.05
+    # both scaling modes are in the line: `value` is the weak one, the strong split is predicted from one GPU at N = 1
+    sec = d["secondary"]
+    assert abs(sec["weak_scaling"]["frames_per_s"] - d["value"]) <= 1e-9 * d["value"]
+    splits = sec["strong_scaling_prediction_from_one_gpu"]["splits"]
+    assert [splits[n]["frames_per_gpu"] for n in ("1", "2", "4", "8")] == [64, 32, 16, 8]
+    assert splits["1"]["predicted_speedup"] == 1.0 and splits["8"]["predicted_speedup"] > 2.0
+    # the other single-GPU BASELINE configs ride in the same line, each with its own roofline and CPU baseline
+    cfg = sec["configs"]
+    assert sorted(cfg) == ["configs[0]", "configs[2]", "configs[3]"]
+    for name, line in cfg.items():
+        assert name in line["config"]["workload"] and line["value"] > 0 and line["ms_per_step"] > 0
+        assert line["roofline"]["bound"] in ("host", "pcie", "hbm") and line["cpu_baseline"]["value"] > 0
+    assert cfg["configs[3]"]["secondary"]["lane_raster_only_ms"] > 0
+    assert sec["configs_wall_s"] < 60
+
+
+def test_bench_strong_mode_reports_the_c4_split(monkeypatch):
+    d = _run_bench(monkeypatch, "--gpus", "1", "--steps", "20", "--warmup", "5", "--scaling", "strong", "--no-configs",
+                   "--no-cpu-baseline")
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and "configs[4]" in d["config"]["workload"]
+    st = d["secondary"]["strong_scaling"]
+    assert st["total_frames"] == 64 and st["frames_per_rank"] == [64] and st["range_this_rank"] == [0, 64]
+    assert abs(d["value"] - 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"] and d["ms_per_step"] == st["ms_per_step"]
+    assert st["kernel"].startswith("splat_kernel<PX=4,R=8,CLEAR=1,SM=0>")
+    assert d["secondary"]["weak_scaling"]["frames_per_s"] > 0

@@ -102,3 +102,95 @@ def test_start_copy_numpy_to_cpu_and_passthrough():
     assert isinstance(single, torch.Tensor)
     with pytest.raises(RuntimeError):
         mtc.start_copy([torch.zeros(1)], "not-a-device")
+
+
+def test_invalid_device_string_message():
+    """A malformed device surfaces as RuntimeError("Invalid device string: '…'") — the text the reference extension
+    produces (multi_tensor_copier.cpp:225-232) — with torch's own explanation attached as the cause."""
+    from accvlab.multi_tensor_copier import start_copy
+
+    for bad in ("notadevice", "cuda:x", "gpu0"):
+        with pytest.raises(RuntimeError, match=f"^Invalid device string: '{bad}'") as info:
+            start_copy([torch.zeros(2)], bad)
+        assert info.value.__cause__ is not None
+    with pytest.raises(RuntimeError, match="^Invalid device string: 'meta'"):      # a device type this path does not serve
+        start_copy([torch.zeros(2)], "meta")
+
+
+# ---- life cycle of the library's orchestration thread (ADVICE r2): bounded ticket table, fork, orderly shutdown.
+# Staging-only jobs (device pointer NULL = no transfer) need no GPU; each case runs in a child interpreter because the
+# shutdown is final for a process.
+_LIFECYCLE = r'''
+import ctypes, os, sys
+import numpy as np
+sys.path[:0] = [ROOT, os.path.join(ROOT, "accv-lab_amd")]
+from accvlab import _amd_native as nat
+lib = nat.ctypes_lib()
+
+def stage(n=3, nbytes=64):
+    src = [np.arange(nbytes, dtype=np.uint8) + k for k in range(n)]
+    dst = np.zeros(n * nbytes, dtype=np.uint8)
+    P, L = ctypes.c_void_p, ctypes.c_longlong
+    a_src = (P * n)(*[s.ctypes.data for s in src])
+    a_nb = (L * n)(*([nbytes] * n)); a_off = (L * n)(*[k * nbytes for k in range(n)]); a_ord = (L * n)(*range(n))
+    a_beg = (L * 2)(0, n); a_stg = (P * 1)(dst.ctypes.data); a_dev = (P * 1)(None); a_cb = (L * 1)(n * nbytes)
+    t = L(0)
+    rc = lib.accv_mtc_stage_h2d_async(n, a_src, a_nb, a_off, a_ord, 1, a_beg, a_stg, a_dev, a_cb, None, 1, -1, ctypes.addressof(t))
+    return rc, t.value, dst, src
+'''
+
+
+def _run_child(body):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"ROOT = {root!r}\n" + _LIFECYCLE + body
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    return res.stdout
+
+
+def test_orchestrator_forgets_finished_tickets_nobody_waited_for():
+    out = _run_child(r'''
+import time
+for i in range(1500):                      # never waited for: only polled
+    rc, t, dst, src = stage()
+    assert rc == 0
+    while lib.accv_mtc_async_poll(t) == 0:
+        time.sleep(0)
+held = lib.accv_mtc_async_tickets_held()
+assert held <= 1024 + 1, held              # bounded, not 1500
+rc, t, dst, src = stage()
+assert lib.accv_mtc_async_wait(t) == 0 and bytes(dst[:64]) == bytes(src[0]) and bytes(dst[128:]) == bytes(src[2])
+assert lib.accv_mtc_async_wait(t) != 0     # a ticket is forgotten by the wait that returned its status
+assert lib.accv_mtc_async_wait(1) != 0     # swept long ago
+print("ok")
+''')
+    assert "ok" in out
+
+
+def test_orchestrator_works_in_a_forked_child_and_refuses_jobs_after_shutdown():
+    out = _run_child(r'''
+rc, t, dst, src = stage()
+assert rc == 0 and lib.accv_mtc_async_wait(t) == 0          # the parent's thread exists now
+pid = os.fork()
+if pid == 0:                                                 # child: the parent's thread is gone, a fresh one must start
+    import signal
+    signal.alarm(30)                                         # a hang (the bug this guards against) ends the child
+    rc, t, dst, src = stage()
+    ok = rc == 0 and lib.accv_mtc_async_wait(t) == 0 and bytes(dst[64:128]) == bytes(src[1])
+    os._exit(0 if ok else 1)
+_, status = os.waitpid(pid, 0)
+assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+rc, t, dst, src = stage()
+assert rc == 0
+lib.accv_mtc_shutdown()                                      # drains the queued job first
+assert lib.accv_mtc_async_poll(t) == 1 and lib.accv_mtc_async_wait(t) == 0 and bytes(dst[:64]) == bytes(src[0])
+lib.accv_mtc_shutdown()                                      # idempotent
+rc, t, dst, src = stage()
+assert rc != 0 and b"shut down" in lib.accv_last_error()
+print("ok")
+''')
+    assert "ok" in out

@@ -458,6 +458,10 @@ def test_dispatch_string_follows_the_public_hints(kernel_variant):
     if kernel_variant != "small-splat":
         want = "SM=4" if kernel_variant.endswith("wt-nt") else "SM=0" if kernel_variant == "plain-stores" else "SM=5"
         assert want in s and "CLEAR=0" in s
+    else:
+        # the small-splat kernel has no per-plane choice: point-like objects are the sparse case, i.e. plain stores
+        # unless write-through is asked for explicitly
+        assert s.startswith("splat_small_kernel<") and "SM=0" in s and "CLEAR=0" in s
     # a map whose width is not a multiple of 4 takes the scalar instantiation whatever the hints say
     odd = torch.zeros(1, 8, 30, device=DEV)
     draw_heatmap_batched(odd, rb(c[:1], n[:1]), rb(r[:1], n[:1]))

@@ -15,12 +15,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import matched_loss as ml  # noqa: E402
 
 
-def _run(device, batch, q, c, max_gt, seed, min_gt=0):
+def _run(device, batch, q, c, max_gt, seed, min_gt=0, fused=False):
     inp = ml.make_inputs(batch, q, c, max_gt, device, seed=seed, min_gt=min_gt)
     gb, gl, gw, pb, ps, pe = inp
     leaves_a = [t.clone().requires_grad_(True) for t in (pb, ps, pe)]
     leaves_b = [t.clone().requires_grad_(True) for t in (pb, ps, pe)]
-    la = ml.run_batched(gb, gl, gw, *leaves_a)
+    la = ml.run_batched(gb, gl, gw, *leaves_a, fused=fused)
     lb = ml.loss_per_sample(gb, gl, gw, *leaves_b)
     assert la.shape == lb.shape == (batch,)
     torch.testing.assert_close(la, lb, rtol=1e-5, atol=1e-5)
@@ -39,15 +39,17 @@ def test_indexed_ops_are_gpu_only_like_the_reference():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True], ids=["operators", "fused-class-and-box-terms"])
 @pytest.mark.parametrize("seed", [0, 1])
-def test_matched_loss_gpu(seed):
-    _run(torch.device("cuda", 0), batch=8, q=100, c=10, max_gt=30, seed=seed)
+def test_matched_loss_gpu(seed, fused):
+    _run(torch.device("cuda", 0), batch=8, q=100, c=10, max_gt=30, seed=seed, fused=fused)
 
 
 @pytest.mark.gpu
-def test_matched_loss_gpu_edge_shapes():
-    _run(torch.device("cuda", 0), batch=5, q=4, c=3, max_gt=7, seed=11)
-    _run(torch.device("cuda", 0), batch=3, q=4, c=3, max_gt=0, seed=12)
+@pytest.mark.parametrize("fused", [False, True], ids=["operators", "fused-class-and-box-terms"])
+def test_matched_loss_gpu_edge_shapes(fused):
+    _run(torch.device("cuda", 0), batch=5, q=4, c=3, max_gt=7, seed=11, fused=fused)
+    _run(torch.device("cuda", 0), batch=3, q=4, c=3, max_gt=0, seed=12, fused=fused)
 
 
 def test_match_indices_identical_to_per_frame_assignment():

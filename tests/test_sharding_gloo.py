@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 import bench_workloads as wl
 from accvlab.draw_heatmap.sharding import (all_gather_heatmaps, init_process_group, job_throughput, max_over_ranks,
-                                           rank_layout, rank_seed, shard_range, timed_steps)
+                                           rank_layout, rank_seed, shard_range, strong_scaling_run, timed_steps)
 from oracle import h1 as oracle
 
 H, W, TOTAL = 40, 64, 5
@@ -84,6 +84,7 @@ def _bench_worker(rank, world, port, out_dir):
         seed = rank_seed(42, r)
         centers_l, radii_l = wl.heatmap_objects(4, H, W, 1, 6, "A", seed=seed)
         n_objects = sum(int(x.shape[0]) for x in radii_l)
+        checksum = int(sum(int(c.to(torch.int64).sum()) * (i + 1) for i, c in enumerate(centers_l)))
         calls = []
 
         def step():                       # rank 1 is the slow one
@@ -92,7 +93,7 @@ def _bench_worker(rank, world, port, out_dir):
 
         ms = timed_steps(step, 5, dist=d, sync=None)
         ms_max = max_over_ranks(ms)
-        torch.save({"rank": (r, lr, w), "seed": seed, "n_objects": n_objects, "calls": len(calls), "ms": ms, "ms_max": ms_max,
+        torch.save({"rank": (r, lr, w), "seed": seed, "n_objects": n_objects, "checksum": checksum, "calls": len(calls), "ms": ms, "ms_max": ms_max,
                     "value": job_throughput(4, w, ms_max)}, os.path.join(out_dir, f"b{rank}.pt"))
         d.barrier()
     finally:
@@ -105,7 +106,7 @@ def test_bench_control_flow_on_two_gloo_ranks(tmp_path):
     outs = [torch.load(os.path.join(str(tmp_path), f"b{r}.pt")) for r in range(world)]
     assert [o["rank"] for o in outs] == [(0, 0, 2), (1, 1, 2)]
     assert [o["seed"] for o in outs] == [42, 43]                        # every rank draws its own frames
-    assert outs[0]["n_objects"] != outs[1]["n_objects"] or True
+    assert outs[0]["checksum"] != outs[1]["checksum"]                   # ... the DATA differ, not only the seed integers
     assert all(o["calls"] == 5 for o in outs)                           # exactly K steps inside the timed region
     assert outs[0]["ms_max"] == outs[1]["ms_max"] >= outs[1]["ms"] - 1e-9   # MAX over ranks, identical on both
     assert outs[1]["ms"] >= 4.0 and outs[0]["ms_max"] >= 4.0            # the slow rank (2 x 2 ms sleeps) sets the time
@@ -113,3 +114,57 @@ def test_bench_control_flow_on_two_gloo_ranks(tmp_path):
     assert outs[0]["ms"] >= 0.9 * outs[1]["ms"]
     assert abs(outs[0]["value"] - 2 * 4 / (outs[0]["ms_max"] * 1e-3)) < 1e-6
     assert rank_layout({}) == (0, 0, 1) and init_process_group(1) is None
+
+
+# ---- strong scaling: ONE batch cut over the ranks with shard_range; the function bench.py calls
+S_TOTAL = 7
+
+
+def _strong_worker(rank, world, port, out_dir):
+    import time
+
+    env = {"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world)}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env)
+    r, _, w = rank_layout(env)
+    d = init_process_group(w, backend="gloo")
+    try:
+        centers_l, radii_l = wl.heatmap_objects(S_TOTAL, H, W, 1, 6, "A", seed=42)     # the SAME batch on every rank
+        drawn, made = [], []
+
+        def make_step(lo, hi):
+            made.append((lo, hi))
+
+            def step():
+                drawn.append(_draw(centers_l, radii_l, lo, hi))
+                time.sleep(0.001 * (hi - lo))          # cost grows with the slice: rank 0 (4 frames) is the slow one
+            return step
+
+        res = strong_scaling_run(make_step, S_TOTAL, r, w, steps=3, warmup=2, dist=d, sync=None)
+        res.update(made=made, calls=len(drawn), last=drawn[-1])
+        torch.save(res, os.path.join(out_dir, f"s{rank}.pt"))
+        d.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_strong_scaling_split_on_two_gloo_ranks(tmp_path):
+    world = 2
+    mp.start_processes(_strong_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    outs = [torch.load(os.path.join(str(tmp_path), f"s{r}.pt")) for r in range(world)]
+    assert [o["range_this_rank"] for o in outs] == [[0, 4], [4, 7]] and [o["made"] for o in outs] == [[(0, 4)], [(4, 7)]]
+    assert all(o["frames_per_rank"] == [4, 3] and o["total_frames"] == S_TOTAL for o in outs)
+    assert all(o["calls"] == 2 + 3 for o in outs)                        # warm-up + exactly K timed steps
+    assert outs[0]["ms_per_step"] == outs[1]["ms_per_step"] >= 4.0      # MAX over ranks: the 4-frame slice sets the time
+    assert outs[0]["frames_per_s"] == outs[1]["frames_per_s"] == S_TOTAL / (outs[0]["ms_per_step"] * 1e-3)
+    # the slices put side by side ARE the single-process batch
+    centers_l, radii_l = wl.heatmap_objects(S_TOTAL, H, W, 1, 6, "A", seed=42)
+    assert torch.equal(torch.cat([o["last"] for o in outs]), _draw(centers_l, radii_l, 0, S_TOTAL))
+
+
+def test_strong_scaling_single_process_and_empty_slices():
+    seen = []
+    res = strong_scaling_run(lambda lo, hi: (lambda: seen.append((lo, hi))), 5, 0, 1, steps=4, warmup=1)
+    assert seen == [(0, 5)] * 5 and res["frames_per_rank"] == [5] and res["frames_per_s"] > 0
+    # more ranks than frames: the surplus rank draws nothing (make_step is never called for it) but still reports
+    res = strong_scaling_run(lambda lo, hi: pytest.fail("empty slice must not build a step"), 2, 2, 3, steps=1, warmup=0)
+    assert res["frames_this_rank"] == 0 and res["frames_per_rank"] == [1, 1, 0]
