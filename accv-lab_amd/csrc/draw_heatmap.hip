@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdint>
+#include <cstring>
 
 #include "accv_common.h"
 
@@ -61,6 +62,10 @@ struct SplatParams {
     // point splats (SRC == 2): centers_f = sampled points [B, n_max, 2]; boxes_f = bounding boxes of every 64 consecutive
     // points [B, n_groups, 4] (xmin, ymin, xmax, ymax; source pixels); every point gets the same radius
     int radius, n_groups;
+    // point splats at a fine scale: strip_mode = tiles per strip (1, 2 or 4; one WAVE walks them), 0 = four waves share a tile
+    int strip_mode, strips_y;
+    long long n_strips;   // planes * strips_y * tiles_x
+    long long n_units;    // workgroups this scale takes in the multi-scale launch (tiles, or strips / 4)
 };
 
 constexpr int kMaxScales = 4;
@@ -68,6 +73,10 @@ struct MultiParams {
     SplatParams scale[kMaxScales];
     long long tile_begin[kMaxScales + 1];  // linear workgroup index where each scale's tiles start
     int n_scales;
+    // point splats: the first `mix_units` work units (the coarse scales: long per-tile chains that issue little) are dealt
+    // out one per 2^mix_shift workgroups, the slots between them go to the units behind them (fine scales: store streams)
+    long long mix_units;
+    int mix_shift, walk;
 };
 
 // one culled hit, read back as a single ds_read_b128 broadcast.  The clipped box is stored relative to the tile and
@@ -118,6 +127,8 @@ struct TileCtx {
     int n, cls;              // cls < 0: no class filter
 };
 
+__device__ __forceinline__ void plane_objects(const SplatParams& p, TileCtx& t);
+
 // tile coordinates from the launch geometry + the object range that feeds this plane; false = wave has no tile
 template <int TW, int TH, int WPG>
 __device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, TileCtx& t, long long linear_group)
@@ -149,8 +160,13 @@ __device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, Tile
     t.ty0 = ty * TH;
     t.tx1 = min(t.tx0 + TW, p.W);
     t.ty1 = min(t.ty0 + TH, p.H);
+    plane_objects(p, t);
+    return true;
+}
 
-    // which objects feed this plane: objects [obj_base, obj_base + n) of centers/radii(/labels)
+// which objects feed plane t.plane: objects [obj_base, obj_base + n) of centers/radii(/labels)
+__device__ __forceinline__ void plane_objects(const SplatParams& p, TileCtx& t)
+{
     long long obj_base;
     t.cls = -1;
     if (p.plane_off) {  // flat API: the binning pre-pass left plane-sorted copies of the objects
@@ -174,7 +190,6 @@ __device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, Tile
     t.boxes_f = reinterpret_cast<const float4*>(p.boxes_f) + (p.n_groups > 0 ? (t.plane * p.n_groups) : obj_base);
     t.stride = p.stride;
     t.radius = p.radius;
-    return true;
 }
 
 // One candidate per lane and round, fetched with branch-free loads (index clamped to the last object, result masked).
@@ -457,14 +472,186 @@ __global__ __launch_bounds__(64) void splat_multi_kernel(const MultiParams mp)
 // as the 8704 tiles of the stride-4 map take) — with four waves the groups of a tile are dealt round-robin over the waves
 // (the LDS float-max atomics commute, also across waves), and an empty tile is stored by four waves with two store
 // instructions each instead of one wave with eight.
-template <bool CLEAR, int SM, int SRC, int NW = 1>
-__device__ __forceinline__ void small_body(const SplatParams& p, long long linear_group)
+// ---- pieces shared by the per-tile body (small_body) and the per-strip body (strip_body)
+constexpr int kSmallTW = 128, kSmallTH = 16;
+// LDS row stride of the tile: 128 + 4 floats.  The walk below puts consecutive ROWS of a splat on consecutive lanes; with a
+// stride of 128 floats they would all land on one LDS bank, with 132 they are 4 banks apart (and 16-byte row reads stay aligned)
+constexpr int kSmallLdsW = kSmallTW + 4;
+constexpr int kSmallTileBytes = kSmallTH * kSmallLdsW * 4;
+using SmallTile = float (*)[kSmallLdsW];
+
+// compaction of one cull round into the wave's hit list, then the hits' boxes are walked.  Round 3: a lane takes one ROW of
+// one hit and runs along its columns (a radius-2 sample: 5 rows -> 12 hits per pass, 5 updates per lane; before: 16 lanes per
+// hit, 2 passes of ~25 instructions for 25 pixels — the per-tile launch was VALU-issue bound, profiles/r03_rocprof_configs/).
+// Pixel updates are LDS float-max atomics (ds_max_f32, no return value): they commute, so neither overlapping boxes of
+// concurrent hits nor successive hits need any ordering — the wave just streams them.  Returns the hit count.
+template <bool WG_SCOPE>
+__device__ __forceinline__ int splat_round(const SplatParams& p, const TileCtx& t, int lane, unsigned long long m, const Cand& cand,
+                                           Hit* __restrict__ hits, SmallTile tile)
 {
-    constexpr int TW = 128, TH = 16;
-    constexpr int RPW = TH / NW / 2;  // rows per half-wave in the zero / init / read-back passes
+    const int nh = __popcll(m);
+    const bool hit = (m >> lane) & 1ull;
+    Hit mine = Hit{0, 0, 0.0f, 0u};
+    if (hit) {
+        mine = make_hit(p, t, cand.x, cand.y, cand.r);
+        hits[__popcll(m & ((1ull << lane) - 1ull))] = mine;
+    }
+    // tallest clipped box of the round (wave-uniform): rows per hit in the lane mapping below
+    int rows = hit ? (int)(mine.box >> 24) - (int)((mine.box >> 16) & 255u) : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) rows = max(rows, __shfl_xor(rows, d));
+    rows = __builtin_amdgcn_readfirstlane(rows);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifndef ACCV_EXP_ROW_WALK
+    {   // round-2 walk: four hits at a time, 16 lanes per hit over its box in row-major order
+        const int grp = lane >> 4, l16 = lane & 15;
+        for (int h0 = 0; h0 < nh; h0 += 4) {
+            const int h = h0 + grp;
+            if (h >= nh) continue;
+            const Hit hh = hits[h];
+            const int xlo = hh.box & 255u, xhi = (hh.box >> 8) & 255u, ylo = (hh.box >> 16) & 255u, yhi = hh.box >> 24;
+            const int w = xhi - xlo, area = w * (yhi - ylo);
+            const float inv_w = 1.0f / (float)max(w, 1);
+            for (int q = l16; q < area; q += 16) {
+                const int py = (int)(((float)q + 0.5f) * inv_w);
+                const int px = q - py * w;
+                const float dx = (float)(t.tx0 + xlo + px - hh.x), dy = (float)(t.ty0 + ylo + py - hh.y);
+                const float v = p.k * raw_exp2(-(dx * dx + dy * dy) * hh.c2);
+                __hip_atomic_fetch_max(&tile[ylo + py][xlo + px], v, __ATOMIC_RELAXED,
+                                       WG_SCOPE ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+    }
+    if (false) {
+        const int per_pass = rows >= 64 ? 1 : 64 / rows;
+#else
+    if (rows > 0) {
+        const int per_pass = rows >= 64 ? 1 : 64 / rows;
+#endif   // hits per pass; a box taller than 64 rows takes several row passes
+        const int hl = rows >= 64 ? 0 : lane / rows, rl = rows >= 64 ? lane : lane - hl * rows;
+        for (int h0 = 0; h0 < nh; h0 += per_pass) {
+            const int h = h0 + hl;
+            if (h >= nh || hl >= per_pass) continue;
+            const Hit hh = hits[h];
+            const int xlo = hh.box & 255u, xhi = (hh.box >> 8) & 255u, ylo = (hh.box >> 16) & 255u, yhi = hh.box >> 24;
+            for (int py = ylo + rl; py < yhi; py += 64) {   // one trip unless the box is taller than 64 rows
+                const float dy = (float)(t.ty0 + py - hh.y);
+                const float dy2 = dy * dy;
+                float* row = &tile[py][0];
+                for (int px = xlo; px < xhi; ++px) {
+                    const float dx = (float)(t.tx0 + px - hh.x);
+                    const float v = p.k * raw_exp2(-(dx * dx + dy2) * hh.c2);
+                    __hip_atomic_fetch_max(row + px, v, __ATOMIC_RELAXED,
+                                           WG_SCOPE ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+        }
+    }
+    // the next round overwrites the hit list: order it behind this round's reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return nh;
+}
+
+// sample-group bounding box (float, source pixels) of group g; valid = false for an empty group (a group of NaN points keeps
+// xmin = +inf) or a group past the plane's sample count
+struct GroupBox {
+    float x0, y0, x1, y1;
+    bool valid;
+};
+__device__ __forceinline__ GroupBox load_group_box(const SplatParams& p, const TileCtx& t, int g)
+{
+    // the load is UNCONDITIONAL (index clamped; callers run only with n_groups >= 1): its address does not depend on the
+    // plane's sample count, so it is in flight together with the count's load instead of behind it — one dependent round
+    // trip less in front of every tile's first store
+    const float4 v = t.boxes_f[min(g, p.n_groups - 1)];
+    return GroupBox{v.x, v.y, v.z, v.w, g < p.n_groups && g * kCand < t.n && v.x <= v.z};
+}
+// can a sample of the group reach pixel columns [cx0, cx1) x rows [cy0, cy1) of this scale?  CONSERVATIVE and division-free
+// (the exact integer test runs per candidate afterwards): a sample at source x lands on pixel int(x / stride), which lies in
+// (x / stride - 1, x / stride], and is drawn over [pixel - r, pixel + r]; the comparisons below are done in source pixels
+// with one extra pixel of slack on either side for the rounding of the products.
+struct ReachBounds {
+    float xlo, xhi, ylo, yhi;   // the group can reach the region iff box.x1 >= xlo && box.x0 < xhi && (same in y)
+};
+__device__ __forceinline__ ReachBounds reach_bounds(const TileCtx& t, int rc, int cx0, int cx1, int cy0, int cy1)
+{
+    const float r1 = (float)min(rc, 1 << 24) + 2.0f;
+    return ReachBounds{((float)cx0 - r1) * t.stride, ((float)cx1 + r1) * t.stride, ((float)cy0 - r1) * t.stride,
+                       ((float)cy1 + r1) * t.stride};
+}
+__device__ __forceinline__ bool group_reaches(const GroupBox& b, const ReachBounds& rb)
+{
+    return b.valid && b.x1 >= rb.xlo && b.x0 < rb.xhi && b.y1 >= rb.ylo && b.y0 < rb.yhi;
+}
+#ifdef ACCV_EXP_DIV_CULL
+// round-2 group test: four IEEE divisions per lane, integer extents
+__device__ __forceinline__ bool group_reaches_div(const GroupBox& b, const TileCtx& t, int rc)
+{
+    constexpr float kClampF = 536870912.0f;
+    if (!b.valid) return false;
+    const int cx0 = (int)fminf(fmaxf(__fdiv_rn(b.x0, t.stride), -kClampF), kClampF);
+    const int cy0 = (int)fminf(fmaxf(__fdiv_rn(b.y0, t.stride), -kClampF), kClampF);
+    const int cx1 = (int)fminf(fmaxf(__fdiv_rn(b.x1, t.stride), -kClampF), kClampF);
+    const int cy1 = (int)fminf(fmaxf(__fdiv_rn(b.y1, t.stride), -kClampF), kClampF);
+    return cx0 - rc < t.tx1 && cx1 + rc >= t.tx0 && cy0 - rc < t.ty1 && cy1 + rc >= t.ty0;
+}
+#endif
+
+// candidates of sample group `g` (one per lane); consecutive samples that land on the same pixel are one and the same splat
+// (coarse scales see several samples per pixel): the first of a run is kept, results are unchanged
+__device__ __forceinline__ Cand load_group_candidates(const TileCtx& t, int sub_base, int lane)
+{
+    Cand c = cull_load<2>(t, sub_base, lane);
+    const int nx = __shfl_up(c.x, 1), ny = __shfl_up(c.y, 1), nr = __shfl_up(c.r, 1);
+    if (lane > 0 && nx == c.x && ny == c.y && nr == c.r) c.r = -1;
+    return c;
+}
+
+template <int SM>
+__device__ __forceinline__ void store_segment(const SplatParams& p, float* plane_ptr, int row, int col0, const vfloat4& v)
+{
+    if constexpr (SM >= 2) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, 18);
+    } else {
+        *reinterpret_cast<vfloat4*>(plane_ptr + (size_t)row * p.W + col0) = v;
+    }
+}
+
+// rows [row0, row0 + RPW) of the finished LDS tile -> the map.  Fused clear: every segment is written (once).  In place: a
+// segment still at its initial value (-inf) received nothing and is neither read nor written.
+template <bool CLEAR, int SM, int RPW>
+__device__ __forceinline__ void write_back_rows(const SplatParams& p, const TileCtx& t, float* plane_ptr, SmallTile tile, int row0,
+                                                int lane, int col0)
+{
+    const float init = CLEAR ? 0.0f : -__builtin_inff();
+    constexpr int kUnroll = RPW > 2 ? 2 : RPW;
+#pragma unroll kUnroll
+    for (int i = 0; i < RPW; ++i) {
+        const int row = t.ty0 + row0 + i;
+        if (row >= p.H) break;
+        vfloat4 out = *reinterpret_cast<const vfloat4*>(&tile[row0 + i][(lane & 31) * 4]);
+        if constexpr (!CLEAR) {
+            if (out.x == init && out.y == init && out.z == init && out.w == init) continue;
+            const vfloat4 old = *reinterpret_cast<const vfloat4*>(plane_ptr + (size_t)row * p.W + col0);
+            const float nanv = __builtin_nanf("");
+            out.x = max_skip_nan(old.x, out.x == init ? nanv : out.x);
+            out.y = max_skip_nan(old.y, out.y == init ? nanv : out.y);
+            out.z = max_skip_nan(old.z, out.z == init ? nanv : out.z);
+            out.w = max_skip_nan(old.w, out.w == init ? nanv : out.w);
+        }
+        store_segment<SM>(p, plane_ptr, row, col0, out);
+    }
+}
+
+template <bool CLEAR, int SM, int SRC, int NW = 1>
+__device__ __forceinline__ void small_body(const SplatParams& p, long long linear_group, Hit (*s_hit)[kCand], SmallTile s_tile)
+{
+    constexpr int TW = kSmallTW, TH = kSmallTH;
+    constexpr int RPW = TH / NW / 2;  // rows per half-wave in the init / read-back passes
     static_assert(TH % (2 * NW) == 0, "rows must split evenly over the half-waves of the workgroup");
-    __shared__ Hit s_hit[NW][kCand];
-    __shared__ __attribute__((aligned(16))) float s_tile[TH][TW];
 
     const int lane = threadIdx.x & 63;
     const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
@@ -474,43 +661,21 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
     const int row0 = wave * (TH / NW) + sub * RPW;               // first of this half-wave's rows
     float* plane_ptr = p.hm + (size_t)t.plane * (size_t)p.H * (size_t)p.W;
 
-    // Round 3: the splats of a lane raster cover a few per cent of the map, and most tiles see no sample at all, so a
-    // fused-clear launch is first of all a FILL.  Every lane stores the zeros of its own 16-byte segments right away —
-    // behind the first (independent) loads of the cull, so that those do not queue behind the stores — and the tile is
-    // only set up in LDS, splatted and written a second time where a sample actually reaches it.  The second store of
-    // a segment comes from the SAME lane as its zeros (program order on one address), and only segments that received a
-    // value are written again: an untouched tile costs two store instructions per wave, no LDS, no barrier, and its
-    // wave never waits for a load it issued after the stores.
-    auto store_segment = [&](int row, const vfloat4& v) {
-        if constexpr (SM >= 2) {
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int)((size_t)p.H * p.W * 4), 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)(((size_t)row * p.W + col0) * 4), 0, 18);
-        } else {
-            *reinterpret_cast<vfloat4*>(plane_ptr + (size_t)row * p.W + col0) = v;
-        }
-    };
-    auto store_zeros = [&]() {
-        if constexpr (CLEAR) {
-            if (col0 < p.W) {
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) {
-                    const int row = t.ty0 + row0 + i;
-                    if (row < p.H) store_segment(row, vfloat4{0.0f, 0.0f, 0.0f, 0.0f});
-                }
-            }
-        }
-    };
-
-    // "untouched" is -inf in the LDS tile (fused-clear mode starts from 0 = the cleared map).  The tile is initialised
-    // lazily, at the first sample (group) that can reach it: the condition is uniform over the workgroup
+    // "untouched" is -inf in the LDS tile (fused-clear mode starts from 0 = the cleared map).  Round 3: the tile is set up
+    // LAZILY, at the first sample (group) that can reach it — a tile nothing reaches (most tiles of a lane raster) costs
+    // no LDS traffic and no barrier: fused clear stores its zeros, in place does nothing.  The condition is uniform over
+    // the workgroup.
     const float init = CLEAR ? 0.0f : -__builtin_inff();
+    // ONE register quad for the initial value: prepare_tile is inlined into every unrolled cull round, and hipcc otherwise
+    // materialises a fresh copy of the constant per store (8 rows x 4 rounds x 4 registers: 188 VGPRs, 2 waves per SIMD)
+    vfloat4 vinit = vfloat4{init, init, init, init};
+    asm volatile("" : "+v"(vinit));
     bool tile_ready = false;
     auto prepare_tile = [&]() {
         if (tile_ready) return;
         tile_ready = true;
 #pragma unroll
-        for (int i = 0; i < RPW; ++i)
-            *reinterpret_cast<vfloat4*>(&s_tile[row0 + i][(lane & 31) * 4]) = vfloat4{init, init, init, init};
+        for (int i = 0; i < RPW; ++i) *reinterpret_cast<vfloat4*>(&s_tile[row0 + i][(lane & 31) * 4]) = vinit;
         if constexpr (NW > 1) {
             __syncthreads();  // tile initialised by all waves before the first atomic of any
         } else {
@@ -518,76 +683,35 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     };
-
-    // one cull round over the 64 candidates [sub_base, sub_base + 64): compaction, then the hits' boxes are walked
+    // one cull round over the 64 candidates [sub_base, sub_base + 64)
     auto process_round = [&](int sub_base, const Cand& cand) {
         const unsigned long long m = cull_test(t, sub_base, lane, cand);
-        const int nh = __popcll(m);
-        if (nh == 0) return;
+        if (m == 0) return;
         if constexpr (NW == 1) prepare_tile();   // (NW > 1: the caller prepared it — a barrier must not sit in per-wave flow)
-        if ((m >> lane) & 1ull) s_hit[wave][__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, cand.x, cand.y, cand.r);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // four hits at a time, 16 lanes per hit walking its box.  Pixel updates are LDS float-max atomics
-        // (ds_max_f32, no return value): they commute, so neither overlapping boxes of concurrent hits nor
-        // successive hits need any ordering — the wave just streams them
-        const int grp = lane >> 4, l16 = lane & 15;
-        for (int h0 = 0; h0 < nh; h0 += 4) {
-            const int h = h0 + grp;
-            if (h >= nh) continue;
-            const Hit hh = s_hit[wave][h];
-            const int xlo = hh.box & 255u, xhi = (hh.box >> 8) & 255u, ylo = (hh.box >> 16) & 255u, yhi = hh.box >> 24;
-            const int w = xhi - xlo, area = w * (yhi - ylo);  // 0 for an empty box
-            const float inv_w = 1.0f / (float)max(w, 1);
-            for (int q = l16; q < area; q += 16) {
-                // q / w for q < 2048, w <= 128: (q + 0.5) / w is at least 1/256 away from an integer, far more
-                // than the error of the reciprocal
-                const int py = (int)(((float)q + 0.5f) * inv_w);
-                const int px = q - py * w;
-                const float dx = (float)(t.tx0 + xlo + px - hh.x), dy = (float)(t.ty0 + ylo + py - hh.y);
-                const float v = p.k * raw_exp2(-(dx * dx + dy * dy) * hh.c2);
-                __hip_atomic_fetch_max(&s_tile[ylo + py][xlo + px], v, __ATOMIC_RELAXED,
-                                       NW > 1 ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-        }
-        // the next round overwrites the hit list: order it behind this round's reads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        splat_round<(NW > 1)>(p, t, lane, m, cand, s_hit[wave], s_tile);
     };
 
     if constexpr (SRC == 2) {
         // two-level cull: consecutive polyline samples are neighbours in space, so each group of 64 carries a
         // bounding box (group_boxes_kernel); a lane tests one GROUP, and only groups that can reach the tile are
         // walked candidate by candidate — a tile crossed by a lane visits 1-3 rounds instead of all of them
-        constexpr float kClampF = 536870912.0f;  // 2^29, as in the integer cull
-        const float inf = __builtin_inff();
-        auto load_group_box = [&](int g) {
-            return (g < p.n_groups && g * kCand < t.n) ? t.boxes_f[g] : float4{inf, inf, -inf, -inf};
-        };
-        const float4 first_boxes = load_group_box(lane);   // issued BEFORE the zero stores
-        store_zeros();
+        const int rc = min(max(t.radius, 0), 1 << 30);
+        const ReachBounds rb = reach_bounds(t, rc, t.tx0, t.tx1, t.ty0, t.ty1);
         for (int g0 = 0; g0 < p.n_groups; g0 += kCand) {
-            const float4 b = g0 == 0 ? first_boxes : load_group_box(g0 + lane);
-            bool ghit = false;
-            if (b.x <= b.z) {  // not empty (a group of NaN points keeps xmin = +inf)
-                const int cx0 = (int)fminf(fmaxf(__fdiv_rn(b.x, t.stride), -kClampF), kClampF);
-                const int cy0 = (int)fminf(fmaxf(__fdiv_rn(b.y, t.stride), -kClampF), kClampF);
-                const int cx1 = (int)fminf(fmaxf(__fdiv_rn(b.z, t.stride), -kClampF), kClampF);
-                const int cy1 = (int)fminf(fmaxf(__fdiv_rn(b.w, t.stride), -kClampF), kClampF);
-                const int rc = min(max(t.radius, 0), 1 << 30);
-                ghit = cx0 - rc < t.tx1 && cx1 + rc >= t.tx0 && cy0 - rc < t.ty1 && cy1 + rc >= t.ty0;
-            }
-            unsigned long long mg = __ballot(ghit);
+#ifdef ACCV_EXP_DIV_CULL
+            unsigned long long mg = __ballot(group_reaches_div(load_group_box(p, t, g0 + lane), t, rc));
+#else
+            unsigned long long mg = __ballot(group_reaches(load_group_box(p, t, g0 + lane), rb));
+#endif
             if (mg == 0) continue;
             if constexpr (NW > 1) {  // every wave found the same groups; this one walks the (k * NW + wave)-th of them
-                prepare_tile();      // uniform over the workgroup: all waves see the same mg here
                 unsigned long long mine = 0;
                 int k = 0;
                 for (unsigned long long rest = mg; rest; rest &= rest - 1, ++k)
                     if (k % NW == wave) mine |= rest & (~rest + 1ull);
                 mg = mine;
             }
-            while (mg) {  // wave-uniform; the candidates of up to four groups are fetched together (one round trip)
+            do {  // wave-uniform; the candidates of up to four groups are fetched together (one round trip)
                 constexpr int kFetch = 4;
                 int sub_base[kFetch];
                 Cand cand[kFetch];
@@ -597,34 +721,27 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
                     if (mg) {
                         sub_base[u] = (g0 + __builtin_ctzll(mg)) * kCand;
                         mg &= mg - 1;
-                        cand[u] = cull_load<2>(t, sub_base[u], lane);
-                        // consecutive samples that land on the same pixel are one and the same splat (coarse scales see
-                        // several samples per pixel): keep the first of a run, results are unchanged
-                        const int nx = __shfl_up(cand[u].x, 1), ny = __shfl_up(cand[u].y, 1), nr = __shfl_up(cand[u].r, 1);
-                        if (lane > 0 && nx == cand[u].x && ny == cand[u].y && nr == cand[u].r) cand[u].r = -1;
+                        cand[u] = load_group_candidates(t, sub_base[u], lane);
                     }
                 }
+                // NW > 1: the tile is set up (LDS writes + a barrier, uniform over the workgroup: every wave saw the same
+                // groups and comes through here even when none of them is its own) BEHIND the candidate requests, so that
+                // the barrier overlaps their flight
+                if constexpr (NW > 1) prepare_tile();
 #pragma unroll
                 for (int u = 0; u < kFetch; ++u)
                     if (sub_base[u] >= 0) process_round(sub_base[u], cand[u]);
-            }
+            } while (mg);
         }
     } else {
         static_assert(SRC == 2 || NW == 1, "the candidate-level cull prepares the tile per wave");
         // long object lists are the normal case here (10^3 lane samples per plane) and the wave needs few registers,
         // so the candidate loads of kFetch rounds are issued together: one memory round trip per kFetch * 64 candidates
         constexpr int kFetch = 4;
-        Cand cand[kFetch];
-        if (t.n > 0) {
-#pragma unroll
-            for (int u = 0; u < kFetch; ++u) cand[u] = cull_load<SRC>(t, u * kCand, lane);   // BEFORE the zero stores
-        }
-        store_zeros();
         for (int base = 0; base < t.n; base += kFetch * kCand) {
-            if (base > 0) {
+            Cand cand[kFetch];
 #pragma unroll
-                for (int u = 0; u < kFetch; ++u) cand[u] = cull_load<SRC>(t, base + u * kCand, lane);
-            }
+            for (int u = 0; u < kFetch; ++u) cand[u] = cull_load<SRC>(t, base + u * kCand, lane);
 #pragma unroll
             for (int u = 0; u < kFetch; ++u) {
                 const int sub_base = base + u * kCand;
@@ -634,7 +751,18 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         }
     }
 
-    if (!tile_ready) return;   // nothing reached the tile: fused clear = the zeros above, in place = no HBM traffic at all
+    if (!tile_ready) {   // nothing reached the tile: fused clear = zeros, in place = no HBM traffic at all
+        if constexpr (CLEAR) {
+            if (col0 < p.W) {
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    const int row = t.ty0 + row0 + i;
+                    if (row < p.H) store_segment<SM>(p, plane_ptr, row, col0, vfloat4{0.0f, 0.0f, 0.0f, 0.0f});
+                }
+            }
+        }
+        return;
+    }
     if constexpr (NW > 1) {
         __syncthreads();  // all atomics of all waves landed before the tile is read back
     } else {
@@ -642,43 +770,199 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (col0 >= p.W) return;
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int row = t.ty0 + row0 + i;
-        if (row >= p.H) break;
-        vfloat4 out = *reinterpret_cast<const vfloat4*>(&s_tile[row0 + i][(lane & 31) * 4]);
-        // a segment still at its initial value received nothing.  Fused clear: its zeros are already on their way
-        // (bit pattern test: a -0.0 that a negative k produced is written as before).  In place: not read, not written
-        const unsigned ibits = __float_as_uint(init);
-        if (__float_as_uint(out.x) == ibits && __float_as_uint(out.y) == ibits && __float_as_uint(out.z) == ibits &&
-            __float_as_uint(out.w) == ibits)
-            continue;
-        if constexpr (!CLEAR) {
-            const vfloat4 old = *reinterpret_cast<const vfloat4*>(plane_ptr + (size_t)row * p.W + col0);
-            const float nanv = __builtin_nanf("");
-            out.x = max_skip_nan(old.x, out.x == init ? nanv : out.x);
-            out.y = max_skip_nan(old.y, out.y == init ? nanv : out.y);
-            out.z = max_skip_nan(old.z, out.z == init ? nanv : out.z);
-            out.w = max_skip_nan(old.w, out.w == init ? nanv : out.w);
-        }
-        store_segment(row, out);
-    }
+    write_back_rows<CLEAR, SM, RPW>(p, t, plane_ptr, s_tile, row0, lane, col0);
 }
 
 template <bool CLEAR, int SM>
 __global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
 {
-    small_body<CLEAR, SM, 0>(p, blockIdx.x);
+    __shared__ Hit s_hit[1][kCand];
+    __shared__ __attribute__((aligned(16))) float s_tile[kSmallTH][kSmallLdsW];
+    small_body<CLEAR, SM, 0>(p, blockIdx.x, s_hit, s_tile);
 }
 
-// lane rasters of all scales in one launch: float sample points, two-level cull (SRC = 2), scale from the tile prefix
-// NW = 4 when some scale is coarse enough for a tile to see many samples (decided on the host), else one wave per tile
+// lane rasters of all scales in one launch, ONE tile per workgroup of NW waves (round 2's shape): scale from the tile prefix
 template <bool CLEAR, int SM, int NW>
-__global__ __launch_bounds__(NW * 64) void splat_points_multi_kernel(const MultiParams mp)
+__global__ __launch_bounds__(NW * 64) void splat_points_tile_kernel(const MultiParams mp)
 {
+    __shared__ Hit s_hit[NW][kCand];
+    __shared__ __attribute__((aligned(16))) float s_tile[kSmallTH][kSmallLdsW];
+    long long u = blockIdx.x;
+    if (mp.mix_shift > 0 && u < (mp.mix_units << mp.mix_shift)) {
+        const long long g = u >> mp.mix_shift, r = u & ((1ll << mp.mix_shift) - 1);
+        u = r == 0 ? g : mp.mix_units + g * ((1ll << mp.mix_shift) - 1) + (r - 1);
+    }
     int s = 0;
-    while (s + 1 < mp.n_scales && (long long)blockIdx.x >= mp.tile_begin[s + 1]) ++s;
-    small_body<CLEAR, SM, 2, NW>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s]);
+    while (s + 1 < mp.n_scales && u >= mp.tile_begin[s + 1]) ++s;
+    small_body<CLEAR, SM, 2, NW>(mp.scale[s], u - mp.tile_begin[s], s_hit, s_tile);
+}
+
+// ---------------------------------------------------------------- point splats at a fine scale: one wave per STRIP
+// Round 3.  At a fine scale (stride 4 of config 3: 8704 tiles) most tiles of a lane raster see no sample and the others
+// one or two sample groups.  PMC of the per-tile kernel (profiles/r03_rocprof_configs/c3_pmc_issue_mix_before_*.json): a wave
+// lives ~5 us and waits for 77 % of that — kernel arguments -> sample count -> group boxes -> candidates -> LDS -> store is
+// a chain of dependent round trips, and with four waves per tile only 8 tiles (64 KB of map) are in flight per CU:
+// 8 x 8 KB / 5 us x 256 CUs = 3.3 TB/s, which is what the launch delivered.  Here ONE wave owns TPS vertically
+// consecutive tiles (TPS = 4: 128 x 64 px): the group boxes are fetched and converted once per strip and kept in registers, an
+// untouched strip is 32 back-to-back store instructions, and for a touched strip the candidates of tile q + 1 are
+// requested BEFORE the stores of tile q are issued (vector loads queue behind older stores of the same wave, never behind
+// younger ones).  Four such waves form a workgroup (4 x 9 KB of LDS): 16 strips = 512 KB of map in flight per CU.
+constexpr int kStripFetch = 4;   // sample groups whose candidates are requested together
+struct StripBatch {
+    int sub_base[kStripFetch];    // first sample of each fetched group, -1 = none
+    Cand cand[kStripFetch];
+    unsigned long long rest;      // groups of the tile's first cull round that did not fit this batch
+};
+
+// TPS = tiles per strip (1: a wave per tile)
+template <bool CLEAR, int SM, int TPS>
+__device__ __forceinline__ void strip_body(const SplatParams& p, long long strip, Hit* __restrict__ s_hit, SmallTile s_tile)
+{
+    constexpr int TW = kSmallTW, TH = kSmallTH, RPW = TH / 2;
+    if (strip >= p.n_strips) return;   // whole wave; waves of a strip workgroup never synchronise with each other
+    const int lane = threadIdx.x & 63;
+    TileCtx t;
+    int sy;
+    if (p.n_strips <= 0x7fffffffll) {
+        const unsigned s32 = (unsigned)strip, s2 = s32 / (unsigned)p.tiles_x;
+        const unsigned pl = s2 / (unsigned)p.strips_y;
+        t.tx0 = (int)(s32 - s2 * (unsigned)p.tiles_x) * TW;
+        sy = (int)(s2 - pl * (unsigned)p.strips_y);
+        t.plane = pl;
+    } else {
+        const long long s2 = strip / p.tiles_x;
+        t.tx0 = (int)(strip % p.tiles_x) * TW;
+        sy = (int)(s2 % p.strips_y);
+        t.plane = s2 / p.strips_y;
+    }
+    t.tx1 = min(t.tx0 + TW, p.W);
+    const int sy0 = sy * (TPS * TH), sy1 = min(sy0 + TPS * TH, p.H);
+    t.ty0 = sy0;
+    t.ty1 = sy1;
+    plane_objects(p, t);
+    const int sub = lane >> 5, col0 = t.tx0 + (lane & 31) * 4;
+    const int row0 = sub * RPW;
+    float* plane_ptr = p.hm + (size_t)t.plane * (size_t)p.H * (size_t)p.W;
+    const int rc = min(max(t.radius, 0), 1 << 30);
+
+    // the first 64 sample groups of the plane, one per lane, kept in registers for all tiles of the strip
+    const GroupBox gbox = load_group_box(p, t, lane);
+    auto reach = [&](const GroupBox& b, int ylo, int yhi) {
+        return __ballot(group_reaches(b, reach_bounds(t, rc, t.tx0, t.tx1, ylo, yhi)));
+    };
+    auto zero_rows = [&](int ylo, int yhi) {   // rows [ylo, yhi): two rows per store instruction
+        if (col0 < p.W)
+            for (int row = ylo + sub; row < yhi; row += 2) store_segment<SM>(p, plane_ptr, row, col0, vfloat4{0.0f, 0.0f, 0.0f, 0.0f});
+    };
+    const bool one_round = p.n_groups <= kCand;
+    if (TPS > 1 && one_round && reach(gbox, sy0, sy1) == 0) {   // nothing reaches the strip
+        if constexpr (CLEAR) zero_rows(sy0, sy1);
+        return;
+    }
+
+    auto fetch = [&](unsigned long long mg, StripBatch& b) {   // requests the candidates of the first kStripFetch groups of mg
+#pragma unroll
+        for (int u = 0; u < kStripFetch; ++u) {
+            b.sub_base[u] = -1;
+            if (mg) {
+                b.sub_base[u] = __builtin_ctzll(mg) * kCand;
+                mg &= mg - 1;
+                b.cand[u] = load_group_candidates(t, b.sub_base[u], lane);
+            }
+        }
+        b.rest = mg;
+    };
+
+    const float init = CLEAR ? 0.0f : -__builtin_inff();
+    vfloat4 vinit = vfloat4{init, init, init, init};
+    asm volatile("" : "+v"(vinit));   // one register quad for all inlined copies of the tile set-up (see small_body)
+    StripBatch next;
+    fetch(reach(gbox, sy0, min(sy0 + TH, p.H)), next);
+#pragma unroll 1
+    for (int q = 0; q < TPS; ++q) {
+        t.ty0 = sy0 + q * TH;
+        if (t.ty0 >= p.H) break;
+        t.ty1 = min(t.ty0 + TH, p.H);
+        const StripBatch cur = next;
+        // tile q + 1: its candidates are requested now, i.e. before this tile's stores
+        if (TPS > 1 && q + 1 < TPS && t.ty1 < p.H) fetch(reach(gbox, t.ty1, min(t.ty1 + TH, p.H)), next);
+
+        bool tile_ready = false;
+        auto process_round = [&](int sub_base, const Cand& cand) {
+            const unsigned long long m = cull_test(t, sub_base, lane, cand);
+            if (m == 0) return;
+            if (!tile_ready) {
+                tile_ready = true;
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) *reinterpret_cast<vfloat4*>(&s_tile[row0 + i][(lane & 31) * 4]) = vinit;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile initialised before the first atomic
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            splat_round<false>(p, t, lane, m, cand, s_hit, s_tile);
+        };
+#pragma unroll
+        for (int u = 0; u < kStripFetch; ++u)
+            if (cur.sub_base[u] >= 0) process_round(cur.sub_base[u], cur.cand[u]);
+        // rare: more than kStripFetch groups of the first round reach this tile, or the plane has more than 64 groups
+        for (unsigned long long mg = cur.rest; mg;) {
+            StripBatch more;
+            fetch(mg, more);
+            mg = more.rest;
+#pragma unroll
+            for (int u = 0; u < kStripFetch; ++u)
+                if (more.sub_base[u] >= 0) process_round(more.sub_base[u], more.cand[u]);
+        }
+        for (int g0 = kCand; g0 < p.n_groups; g0 += kCand) {
+            for (unsigned long long mg = reach(load_group_box(p, t, g0 + lane), t.ty0, t.ty1); mg; mg &= mg - 1) {
+                const int sub_base = (g0 + __builtin_ctzll(mg)) * kCand;
+                process_round(sub_base, load_group_candidates(t, sub_base, lane));
+            }
+        }
+
+        if (!tile_ready) {
+            if constexpr (CLEAR) zero_rows(t.ty0, t.ty1);
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // all atomics landed before the tile is read back
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (col0 < p.W) write_back_rows<CLEAR, SM, RPW>(p, t, plane_ptr, s_tile, row0, lane, col0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile re-initialises the LDS tile behind these reads
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// lane rasters of all scales in one launch of 256-thread workgroups: float sample points, two-level cull, scale from the
+// workgroup prefix.  Per scale (chosen on the host): COARSE — a tile is crossed by several lanes and has many sample groups
+// to walk, the four waves share ONE tile (small_body, NW = 4); FINE — the four waves own four neighbouring strips of
+// 1, 2 or 4 vertically consecutive tiles and never meet.  Both carve the same 4 x 9.25 KB of LDS.
+template <bool CLEAR, int SM>
+__global__ __launch_bounds__(256) void splat_points_multi_kernel(const MultiParams mp)
+{
+    constexpr int kWaveLds = kSmallTileBytes + kCand * (int)sizeof(Hit);   // tile + 1 KB hit list
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kWaveLds];
+    long long u = blockIdx.x;
+    if (mp.mix_shift > 0 && u < (mp.mix_units << mp.mix_shift)) {
+        const long long g = u >> mp.mix_shift, r = u & ((1ll << mp.mix_shift) - 1);
+        u = r == 0 ? g : mp.mix_units + g * ((1ll << mp.mix_shift) - 1) + (r - 1);
+    }
+    int s = 0;
+    while (s + 1 < mp.n_scales && u >= mp.tile_begin[s + 1]) ++s;
+    const long long unit = u - mp.tile_begin[s];
+    const int tps = mp.scale[s].strip_mode;
+    if (tps) {
+        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        unsigned char* mine = lds + wave * kWaveLds;
+        Hit* hits = reinterpret_cast<Hit*>(mine + kSmallTileBytes);
+        if (tps == 1)
+            strip_body<CLEAR, SM, 1>(mp.scale[s], unit * 4 + wave, hits, reinterpret_cast<SmallTile>(mine));
+        else if (tps == 2)
+            strip_body<CLEAR, SM, 2>(mp.scale[s], unit * 4 + wave, hits, reinterpret_cast<SmallTile>(mine));
+        else
+            strip_body<CLEAR, SM, 4>(mp.scale[s], unit * 4 + wave, hits, reinterpret_cast<SmallTile>(mine));
+    } else {
+        small_body<CLEAR, SM, 2, 4>(mp.scale[s], unit, reinterpret_cast<Hit(*)[kCand]>(lds + kSmallTileBytes),
+                                    reinterpret_cast<SmallTile>(lds));
+    }
 }
 
 // bounding box (xmin, ymin, xmax, ymax) of every 64 consecutive points of points[b, :, :] (NaN points ignored; a group
@@ -1311,7 +1595,36 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
     mp.tile_begin[used] = tiles;
     if (used == 0 || tiles == 0) return ACCV_OK;
     if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: %lld tiles exceed the grid limit", tiles);
+    // per scale: a tile of a COARSE scale is crossed by several lanes and has many sample groups to walk — its four waves
+    // share the tile (>= 24 samples per tile on average; config 3: 7.5 / 30 / 113 at strides 4 / 8 / 16); a FINE scale is
+    // mostly empty tiles — strip mode, one wave per strip of tiles, four strips per workgroup
+    for (int i = 0; i < used; ++i) {
+        SplatParams& p = mp.scale[i];
+        bool coarse = (double)batch * num_points >= 24.0 * (double)p.n_tiles;
+        int tps = 1;
+        if (const int mode = accv::tune_get("pts_mode", -1); mode >= 0) coarse = mode == 0;   // A/B build only
+        if (const int k = accv::tune_get("pts_tps", -1); k == 1 || k == 2 || k == 4) tps = k;
+        p.strip_mode = coarse ? 0 : tps;
+        p.strips_y = (p.tiles_y + tps - 1) / tps;
+        p.n_strips = (long long)batch * p.strips_y * p.tiles_x;
+        p.n_units = coarse ? p.n_tiles : (p.n_strips + 3) / 4;
+    }
     if (!(flags & ACCV_HM_CALLER_SCALE_ORDER)) coarse_scales_first(mp);
+    long long units = 0;
+    for (int i = 0; i < used; ++i) {
+        mp.tile_begin[i] = units;
+        units += mp.scale[i].n_units;
+    }
+    mp.tile_begin[used] = units;
+    {   // interleave: coarse units (they come first) one per 2^shift workgroups while enough fine units remain to fill the gaps
+        long long coarse_units = 0;
+        for (int i = 0; i < used; ++i)
+            if (!mp.scale[i].strip_mode && mp.tile_begin[i] == coarse_units) coarse_units += mp.scale[i].n_units;
+        int shift = accv::tune_get("pts_mix", 0);
+        while (shift > 0 && (coarse_units << shift) > units) --shift;   // bijection needs (2^shift - 1) * coarse <= the rest
+        mp.mix_units = coarse_units;
+        mp.mix_shift = (coarse_units > 0 && coarse_units < units) ? shift : 0;
+    }
     const long long total_groups = (long long)batch * n_groups;
     if (total_groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: too many point groups");
     if (total_groups > 0 && !(flags & ACCV_HM_GROUP_BOXES_GIVEN))
@@ -1320,34 +1633,68 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
                            static_cast<float4*>(workspace));
     int nt = accv::tune_get("hm_nt", -1);
     if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;
-    // a tile of a coarse scale is crossed by several lanes and has many sample groups to walk: share it among four waves
-    // when some scale averages >= 24 samples per tile (config 3: 7.5 / 30 / 113 at strides 4 / 8 / 16); fine scales alone
-    // keep one wave per tile (mostly empty tiles would only pay the barriers: 21.7 -> 23.8 us at stride 4)
-    bool heavy = false;
-    for (int i = 0; i < used; ++i)
-        heavy = heavy || (double)batch * num_points >= 24.0 * (double)mp.scale[i].n_tiles;
-    if (const int nw = accv::tune_get("pts_nw", -1); nw > 0) heavy = nw == 4;   // A/B build only
-    const dim3 grid((unsigned)tiles), block(heavy ? 256 : 64);
-#define ACCV_LAUNCH_POINTS(CL, SMV)                                                                       \
-    do {                                                                                                  \
-        if (heavy)                                                                                        \
-            hipLaunchKernelGGL((splat_points_multi_kernel<CL, SMV, 4>), grid, block, 0, stream, mp);      \
-        else                                                                                              \
-            hipLaunchKernelGGL((splat_points_multi_kernel<CL, SMV, 1>), grid, block, 0, stream, mp);      \
+    if (accv::tune_get("pts_kernel", 0) == 0) {
+        // one tile per workgroup: four waves share a tile when some scale is coarse, else one wave per tile
+        bool heavy = false;
+        long long tiles = 0, coarse_tiles = 0;
+        for (int i = 0; i < used; ++i) {
+            heavy = heavy || mp.scale[i].strip_mode == 0;
+            if (mp.scale[i].strip_mode == 0 && coarse_tiles == tiles) coarse_tiles += mp.scale[i].n_tiles;
+            mp.scale[i].strip_mode = 0;
+            mp.tile_begin[i] = tiles;
+            tiles += mp.scale[i].n_tiles;
+        }
+        mp.tile_begin[used] = tiles;
+        {
+            int shift = accv::tune_get("pts_mix", 0);
+            while (shift > 0 && (coarse_tiles << shift) > tiles) --shift;
+            mp.mix_units = coarse_tiles;
+            mp.mix_shift = (coarse_tiles > 0 && coarse_tiles < tiles) ? shift : 0;
+        }
+        if (const int nw = accv::tune_get("pts_nw", -1); nw > 0) heavy = nw == 4;   // A/B build only
+        const dim3 grid((unsigned)tiles), block(heavy ? 256 : 64);
+#define ACCV_LAUNCH_POINTS(CL, SMV)                                                                  \
+    do {                                                                                             \
+        if (heavy)                                                                                   \
+            hipLaunchKernelGGL((splat_points_tile_kernel<CL, SMV, 4>), grid, block, 0, stream, mp);  \
+        else                                                                                         \
+            hipLaunchKernelGGL((splat_points_tile_kernel<CL, SMV, 1>), grid, block, 0, stream, mp);  \
     } while (0)
+        if (clear) {
+            if (nt >= 2)
+                ACCV_LAUNCH_POINTS(true, 4);
+            else
+                ACCV_LAUNCH_POINTS(true, 0);
+        } else {
+            if (nt >= 2)
+                ACCV_LAUNCH_POINTS(false, 4);
+            else
+                ACCV_LAUNCH_POINTS(false, 0);
+        }
+#undef ACCV_LAUNCH_POINTS
+        note_dispatch("splat_points_tile_kernel", 4, 8, clear, nt >= 2 ? 4 : 0, grid, block);
+        return accv::check_launch("draw_heatmap multi-scale point splat kernel");
+    }
+    const dim3 grid((unsigned)units), block(256);
     if (clear) {
         if (nt >= 2)
-            ACCV_LAUNCH_POINTS(true, 4);
+            hipLaunchKernelGGL((splat_points_multi_kernel<true, 4>), grid, block, 0, stream, mp);
         else
-            ACCV_LAUNCH_POINTS(true, 0);
+            hipLaunchKernelGGL((splat_points_multi_kernel<true, 0>), grid, block, 0, stream, mp);
     } else {
         if (nt >= 2)
-            ACCV_LAUNCH_POINTS(false, 4);
+            hipLaunchKernelGGL((splat_points_multi_kernel<false, 4>), grid, block, 0, stream, mp);
         else
-            ACCV_LAUNCH_POINTS(false, 0);
+            hipLaunchKernelGGL((splat_points_multi_kernel<false, 0>), grid, block, 0, stream, mp);
     }
-#undef ACCV_LAUNCH_POINTS
     note_dispatch("splat_points_multi_kernel", 4, 8, clear, nt >= 2 ? 4 : 0, grid, block);
+    {   // which scales (in launch order) run strip mode ('s') and which share a tile among four waves ('t')
+        char modes[kMaxScales + 1] = {0};
+        for (int i = 0; i < used; ++i) modes[i] = mp.scale[i].strip_mode ? 's' : 't';   // ('s': strip_mode tiles per wave)
+        char* buf = accv::dispatch_buffer();
+        const size_t len = strlen(buf);
+        snprintf(buf + len, 256 - len, " scale_modes(%s)", modes);
+    }
     return accv::check_launch("draw_heatmap multi-scale point splat kernel");
 }
 

@@ -34,11 +34,11 @@ def main():
     dev = torch.device("cuda", 0)
     lib = nat.lib()
     libs = {"shipped": lib}
-    if "--alt-lib" in sys.argv:
-        alt = ctypes.CDLL(os.path.abspath(sys.argv[sys.argv.index("--alt-lib") + 1]))
+    for path in [a for a in sys.argv[1:] if a.endswith(".so")]:      # --alt-lib a.so b.so ...: further builds, same process
+        alt = ctypes.CDLL(os.path.abspath(path))
         alt.accv_draw_points_multiscale_f32.restype, alt.accv_draw_points_multiscale_f32.argtypes = \
             nat.SIGNATURES["accv_draw_points_multiscale_f32"]
-        libs["alt"] = alt
+        libs[os.path.basename(path).replace("libaccv_hip_", "").replace(".so", "")] = alt
     B, SH, SW, L, P, Q = 32, 2160, 3840, 8, 24, 256
     g = torch.Generator().manual_seed(7)
     x0 = torch.rand(B, L, 1, generator=g) * SW
@@ -78,12 +78,30 @@ def main():
         return out
 
     full = torch.full((B,), n, dtype=torch.int32, device=dev)
+    if "--sweep" in sys.argv:
+        # A/B build only (make -C accv-lab_amd/csrc tune; ACCV_HIP_LIB=.../libaccv_hip_tune.so): per-scale mode of the point splat
+        none_ = torch.zeros(B, dtype=torch.int32, device=dev)
+        for name, knobs in (("tile kernel, scales one after the other (coarse first)", {"pts_kernel": 0, "pts_mix": 0}),
+                            ("tile kernel, a coarse tile every 2nd workgroup", {"pts_kernel": 0, "pts_mix": 1}),
+                            ("tile kernel, a coarse tile every 4th workgroup", {"pts_kernel": 0, "pts_mix": 2}),
+                            ("unified kernel (coarse: 4 waves per tile, fine: wave per tile)", {"pts_kernel": 1, "pts_mode": -1, "pts_tps": 1, "pts_mix": 0})):
+            for k, v in knobs.items():
+                nat.tune_set(k, v)
+            row = {"mode": name}
+            for sc, strides in (("all", (4.0, 8.0, 16.0)), ("s4", (4.0,)), ("s8", (8.0,)), ("s16", (16.0,))):
+                row[sc] = {"empty": run(strides, none_, 2)["shipped"]["us"], "8 lanes r=2": run(strides, full, 2)["shipped"]["us"],
+                           "in-place": run(strides, full, 2, clear=False)["shipped"]["us"]}
+            print(json.dumps(row))
+        return
     none = torch.zeros(B, dtype=torch.int32, device=dev)
     one = torch.full((B,), Q, dtype=torch.int32, device=dev)
+    brief = "--brief" in sys.argv
     for name, strides in (("all", (4.0, 8.0, 16.0)), ("s4", (4.0,)), ("s8", (8.0,)), ("s16", (16.0,))):
-        print(json.dumps({"scales": name, "no lanes (empty-tile floor)": run(strides, none, 2),
-                          "1 lane": run(strides, one, 2), "8 lanes r=2": run(strides, full, 2), "8 lanes r=0": run(strides, full, 0),
-                          "8 lanes r=2 in-place": run(strides, full, 2, clear=False)}))
+        res = {"no lanes (empty-tile floor)": run(strides, none, 2), "1 lane": run(strides, one, 2), "8 lanes r=2": run(strides, full, 2),
+               "8 lanes r=0": run(strides, full, 0), "8 lanes r=2 in-place": run(strides, full, 2, clear=False)}
+        if brief:     # one line per case: microseconds per build (+ "!" when a build's map differs from the shipped one)
+            res = {k: {n: (str(v[n]["us"]) + ("" if v[n].get("same_as_shipped", True) else "!")) for n in libs} for k, v in res.items()}
+        print(json.dumps({"scales": name, **res}))
 
 
 if __name__ == "__main__":
