@@ -62,10 +62,6 @@ struct SplatParams {
     // point splats (SRC == 2): centers_f = sampled points [B, n_max, 2]; boxes_f = bounding boxes of every 64 consecutive
     // points [B, n_groups, 4] (xmin, ymin, xmax, ymax; source pixels); every point gets the same radius
     int radius, n_groups;
-    // point splats at a fine scale: strip_mode = tiles per strip (1, 2 or 4; one WAVE walks them), 0 = four waves share a tile
-    int strip_mode, strips_y;
-    long long n_strips;   // planes * strips_y * tiles_x
-    long long n_units;    // workgroups this scale takes in the multi-scale launch (tiles, or strips / 4)
 };
 
 constexpr int kMaxScales = 4;
@@ -73,10 +69,6 @@ struct MultiParams {
     SplatParams scale[kMaxScales];
     long long tile_begin[kMaxScales + 1];  // linear workgroup index where each scale's tiles start
     int n_scales;
-    // point splats: the first `mix_units` work units (the coarse scales: long per-tile chains that issue little) are dealt
-    // out one per 2^mix_shift workgroups, the slots between them go to the units behind them (fine scales: store streams)
-    long long mix_units;
-    int mix_shift, walk;
 };
 
 // one culled hit, read back as a single ds_read_b128 broadcast.  The clipped box is stored relative to the tile and
@@ -472,39 +464,26 @@ __global__ __launch_bounds__(64) void splat_multi_kernel(const MultiParams mp)
 // as the 8704 tiles of the stride-4 map take) — with four waves the groups of a tile are dealt round-robin over the waves
 // (the LDS float-max atomics commute, also across waves), and an empty tile is stored by four waves with two store
 // instructions each instead of one wave with eight.
-// ---- pieces shared by the per-tile body (small_body) and the per-strip body (strip_body)
+// ---- pieces of the per-tile body (small_body)
 constexpr int kSmallTW = 128, kSmallTH = 16;
-// LDS row stride of the tile: 128 + 4 floats.  The walk below puts consecutive ROWS of a splat on consecutive lanes; with a
-// stride of 128 floats they would all land on one LDS bank, with 132 they are 4 banks apart (and 16-byte row reads stay aligned)
-constexpr int kSmallLdsW = kSmallTW + 4;
-constexpr int kSmallTileBytes = kSmallTH * kSmallLdsW * 4;
+constexpr int kSmallLdsW = kSmallTW;
 using SmallTile = float (*)[kSmallLdsW];
 
-// compaction of one cull round into the wave's hit list, then the hits' boxes are walked.  Round 3: a lane takes one ROW of
-// one hit and runs along its columns (a radius-2 sample: 5 rows -> 12 hits per pass, 5 updates per lane; before: 16 lanes per
-// hit, 2 passes of ~25 instructions for 25 pixels — the per-tile launch was VALU-issue bound, profiles/r03_rocprof_configs/).
-// Pixel updates are LDS float-max atomics (ds_max_f32, no return value): they commute, so neither overlapping boxes of
-// concurrent hits nor successive hits need any ordering — the wave just streams them.  Returns the hit count.
+// compaction of one cull round into the wave's hit list, then the hits' boxes are walked: four hits at a time, 16 lanes
+// per hit.  Pixel updates are LDS float-max atomics (ds_max_f32, no return value): they commute, so neither overlapping
+// boxes of concurrent hits nor successive hits need any ordering — the wave just streams them.  Returns the hit count.
+// (Round 3 measured a row-per-lane walk with padded LDS rows — 12 hits per pass instead of 4: -2 % on config 3, +6 % on
+// its stride-4 map alone, i.e. nothing: the launch is bound by the latency chains of its tiles, not by this loop;
+// profiles/r03_lane_splat_variants_walk_cull_vs_prev.log.)
 template <bool WG_SCOPE>
 __device__ __forceinline__ int splat_round(const SplatParams& p, const TileCtx& t, int lane, unsigned long long m, const Cand& cand,
                                            Hit* __restrict__ hits, SmallTile tile)
 {
     const int nh = __popcll(m);
-    const bool hit = (m >> lane) & 1ull;
-    Hit mine = Hit{0, 0, 0.0f, 0u};
-    if (hit) {
-        mine = make_hit(p, t, cand.x, cand.y, cand.r);
-        hits[__popcll(m & ((1ull << lane) - 1ull))] = mine;
-    }
-    // tallest clipped box of the round (wave-uniform): rows per hit in the lane mapping below
-    int rows = hit ? (int)(mine.box >> 24) - (int)((mine.box >> 16) & 255u) : 0;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) rows = max(rows, __shfl_xor(rows, d));
-    rows = __builtin_amdgcn_readfirstlane(rows);
+    if ((m >> lane) & 1ull) hits[__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, cand.x, cand.y, cand.r);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifndef ACCV_EXP_ROW_WALK
-    {   // round-2 walk: four hits at a time, 16 lanes per hit over its box in row-major order
+    {   // four hits at a time, 16 lanes per hit over its box in row-major order
         const int grp = lane >> 4, l16 = lane & 15;
         for (int h0 = 0; h0 < nh; h0 += 4) {
             const int h = h0 + grp;
@@ -520,31 +499,6 @@ __device__ __forceinline__ int splat_round(const SplatParams& p, const TileCtx& 
                 const float v = p.k * raw_exp2(-(dx * dx + dy * dy) * hh.c2);
                 __hip_atomic_fetch_max(&tile[ylo + py][xlo + px], v, __ATOMIC_RELAXED,
                                        WG_SCOPE ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-        }
-    }
-    if (false) {
-        const int per_pass = rows >= 64 ? 1 : 64 / rows;
-#else
-    if (rows > 0) {
-        const int per_pass = rows >= 64 ? 1 : 64 / rows;
-#endif   // hits per pass; a box taller than 64 rows takes several row passes
-        const int hl = rows >= 64 ? 0 : lane / rows, rl = rows >= 64 ? lane : lane - hl * rows;
-        for (int h0 = 0; h0 < nh; h0 += per_pass) {
-            const int h = h0 + hl;
-            if (h >= nh || hl >= per_pass) continue;
-            const Hit hh = hits[h];
-            const int xlo = hh.box & 255u, xhi = (hh.box >> 8) & 255u, ylo = (hh.box >> 16) & 255u, yhi = hh.box >> 24;
-            for (int py = ylo + rl; py < yhi; py += 64) {   // one trip unless the box is taller than 64 rows
-                const float dy = (float)(t.ty0 + py - hh.y);
-                const float dy2 = dy * dy;
-                float* row = &tile[py][0];
-                for (int px = xlo; px < xhi; ++px) {
-                    const float dx = (float)(t.tx0 + px - hh.x);
-                    const float v = p.k * raw_exp2(-(dx * dx + dy2) * hh.c2);
-                    __hip_atomic_fetch_max(row + px, v, __ATOMIC_RELAXED,
-                                           WG_SCOPE ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
             }
         }
     }
@@ -585,19 +539,6 @@ __device__ __forceinline__ bool group_reaches(const GroupBox& b, const ReachBoun
 {
     return b.valid && b.x1 >= rb.xlo && b.x0 < rb.xhi && b.y1 >= rb.ylo && b.y0 < rb.yhi;
 }
-#ifdef ACCV_EXP_DIV_CULL
-// round-2 group test: four IEEE divisions per lane, integer extents
-__device__ __forceinline__ bool group_reaches_div(const GroupBox& b, const TileCtx& t, int rc)
-{
-    constexpr float kClampF = 536870912.0f;
-    if (!b.valid) return false;
-    const int cx0 = (int)fminf(fmaxf(__fdiv_rn(b.x0, t.stride), -kClampF), kClampF);
-    const int cy0 = (int)fminf(fmaxf(__fdiv_rn(b.y0, t.stride), -kClampF), kClampF);
-    const int cx1 = (int)fminf(fmaxf(__fdiv_rn(b.x1, t.stride), -kClampF), kClampF);
-    const int cy1 = (int)fminf(fmaxf(__fdiv_rn(b.y1, t.stride), -kClampF), kClampF);
-    return cx0 - rc < t.tx1 && cx1 + rc >= t.tx0 && cy0 - rc < t.ty1 && cy1 + rc >= t.ty0;
-}
-#endif
 
 // candidates of sample group `g` (one per lane); consecutive samples that land on the same pixel are one and the same splat
 // (coarse scales see several samples per pixel): the first of a run is kept, results are unchanged
@@ -698,11 +639,7 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         const int rc = min(max(t.radius, 0), 1 << 30);
         const ReachBounds rb = reach_bounds(t, rc, t.tx0, t.tx1, t.ty0, t.ty1);
         for (int g0 = 0; g0 < p.n_groups; g0 += kCand) {
-#ifdef ACCV_EXP_DIV_CULL
-            unsigned long long mg = __ballot(group_reaches_div(load_group_box(p, t, g0 + lane), t, rc));
-#else
             unsigned long long mg = __ballot(group_reaches(load_group_box(p, t, g0 + lane), rb));
-#endif
             if (mg == 0) continue;
             if constexpr (NW > 1) {  // every wave found the same groups; this one walks the (k * NW + wave)-th of them
                 unsigned long long mine = 0;
@@ -781,188 +718,24 @@ __global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
     small_body<CLEAR, SM, 0>(p, blockIdx.x, s_hit, s_tile);
 }
 
-// lane rasters of all scales in one launch, ONE tile per workgroup of NW waves (round 2's shape): scale from the tile prefix
+// lane rasters of all scales in one launch: float sample points, two-level cull (SRC = 2), scale from the tile prefix
+// NW = 4 when some scale is coarse enough for a tile to see many samples (decided on the host), else one wave per tile.
+// Round 3 measured the alternatives on config 3 (profiles/r03_lane_splat_*.log): one wave walking a strip of 2 / 4 tiles
+// (empty-tile floor 19.5 -> 16.6 us, but touched tiles then run one after the other on a single wave: 33.5 -> 51 us); a
+// per-scale choice inside one 256-thread launch (fine: a wave per tile, coarse: four waves per tile; 37 KB of LDS and ~100
+// VGPRs for every workgroup halve the resident tiles: 36-37 us); coarse tiles dealt out every 2nd / 4th workgroup instead
+// of first (36 / 43 us: they become the tail); zeros stored ahead of the cull, a row-per-lane walk, a division-free group
+// test, the candidate requests ahead of the tile set-up barrier (all +-2 %).  What bounds the launch is the chain of
+// dependent round trips of each touched tile (kernel arguments -> count / group boxes -> candidates -> LDS -> barrier ->
+// store, ~8 us) times the tiles that fit a CU at once, not an instruction count.
 template <bool CLEAR, int SM, int NW>
-__global__ __launch_bounds__(NW * 64) void splat_points_tile_kernel(const MultiParams mp)
+__global__ __launch_bounds__(NW * 64) void splat_points_multi_kernel(const MultiParams mp)
 {
     __shared__ Hit s_hit[NW][kCand];
     __shared__ __attribute__((aligned(16))) float s_tile[kSmallTH][kSmallLdsW];
-    long long u = blockIdx.x;
-    if (mp.mix_shift > 0 && u < (mp.mix_units << mp.mix_shift)) {
-        const long long g = u >> mp.mix_shift, r = u & ((1ll << mp.mix_shift) - 1);
-        u = r == 0 ? g : mp.mix_units + g * ((1ll << mp.mix_shift) - 1) + (r - 1);
-    }
     int s = 0;
-    while (s + 1 < mp.n_scales && u >= mp.tile_begin[s + 1]) ++s;
-    small_body<CLEAR, SM, 2, NW>(mp.scale[s], u - mp.tile_begin[s], s_hit, s_tile);
-}
-
-// ---------------------------------------------------------------- point splats at a fine scale: one wave per STRIP
-// Round 3.  At a fine scale (stride 4 of config 3: 8704 tiles) most tiles of a lane raster see no sample and the others
-// one or two sample groups.  PMC of the per-tile kernel (profiles/r03_rocprof_configs/c3_pmc_issue_mix_before_*.json): a wave
-// lives ~5 us and waits for 77 % of that — kernel arguments -> sample count -> group boxes -> candidates -> LDS -> store is
-// a chain of dependent round trips, and with four waves per tile only 8 tiles (64 KB of map) are in flight per CU:
-// 8 x 8 KB / 5 us x 256 CUs = 3.3 TB/s, which is what the launch delivered.  Here ONE wave owns TPS vertically
-// consecutive tiles (TPS = 4: 128 x 64 px): the group boxes are fetched and converted once per strip and kept in registers, an
-// untouched strip is 32 back-to-back store instructions, and for a touched strip the candidates of tile q + 1 are
-// requested BEFORE the stores of tile q are issued (vector loads queue behind older stores of the same wave, never behind
-// younger ones).  Four such waves form a workgroup (4 x 9 KB of LDS): 16 strips = 512 KB of map in flight per CU.
-constexpr int kStripFetch = 4;   // sample groups whose candidates are requested together
-struct StripBatch {
-    int sub_base[kStripFetch];    // first sample of each fetched group, -1 = none
-    Cand cand[kStripFetch];
-    unsigned long long rest;      // groups of the tile's first cull round that did not fit this batch
-};
-
-// TPS = tiles per strip (1: a wave per tile)
-template <bool CLEAR, int SM, int TPS>
-__device__ __forceinline__ void strip_body(const SplatParams& p, long long strip, Hit* __restrict__ s_hit, SmallTile s_tile)
-{
-    constexpr int TW = kSmallTW, TH = kSmallTH, RPW = TH / 2;
-    if (strip >= p.n_strips) return;   // whole wave; waves of a strip workgroup never synchronise with each other
-    const int lane = threadIdx.x & 63;
-    TileCtx t;
-    int sy;
-    if (p.n_strips <= 0x7fffffffll) {
-        const unsigned s32 = (unsigned)strip, s2 = s32 / (unsigned)p.tiles_x;
-        const unsigned pl = s2 / (unsigned)p.strips_y;
-        t.tx0 = (int)(s32 - s2 * (unsigned)p.tiles_x) * TW;
-        sy = (int)(s2 - pl * (unsigned)p.strips_y);
-        t.plane = pl;
-    } else {
-        const long long s2 = strip / p.tiles_x;
-        t.tx0 = (int)(strip % p.tiles_x) * TW;
-        sy = (int)(s2 % p.strips_y);
-        t.plane = s2 / p.strips_y;
-    }
-    t.tx1 = min(t.tx0 + TW, p.W);
-    const int sy0 = sy * (TPS * TH), sy1 = min(sy0 + TPS * TH, p.H);
-    t.ty0 = sy0;
-    t.ty1 = sy1;
-    plane_objects(p, t);
-    const int sub = lane >> 5, col0 = t.tx0 + (lane & 31) * 4;
-    const int row0 = sub * RPW;
-    float* plane_ptr = p.hm + (size_t)t.plane * (size_t)p.H * (size_t)p.W;
-    const int rc = min(max(t.radius, 0), 1 << 30);
-
-    // the first 64 sample groups of the plane, one per lane, kept in registers for all tiles of the strip
-    const GroupBox gbox = load_group_box(p, t, lane);
-    auto reach = [&](const GroupBox& b, int ylo, int yhi) {
-        return __ballot(group_reaches(b, reach_bounds(t, rc, t.tx0, t.tx1, ylo, yhi)));
-    };
-    auto zero_rows = [&](int ylo, int yhi) {   // rows [ylo, yhi): two rows per store instruction
-        if (col0 < p.W)
-            for (int row = ylo + sub; row < yhi; row += 2) store_segment<SM>(p, plane_ptr, row, col0, vfloat4{0.0f, 0.0f, 0.0f, 0.0f});
-    };
-    const bool one_round = p.n_groups <= kCand;
-    if (TPS > 1 && one_round && reach(gbox, sy0, sy1) == 0) {   // nothing reaches the strip
-        if constexpr (CLEAR) zero_rows(sy0, sy1);
-        return;
-    }
-
-    auto fetch = [&](unsigned long long mg, StripBatch& b) {   // requests the candidates of the first kStripFetch groups of mg
-#pragma unroll
-        for (int u = 0; u < kStripFetch; ++u) {
-            b.sub_base[u] = -1;
-            if (mg) {
-                b.sub_base[u] = __builtin_ctzll(mg) * kCand;
-                mg &= mg - 1;
-                b.cand[u] = load_group_candidates(t, b.sub_base[u], lane);
-            }
-        }
-        b.rest = mg;
-    };
-
-    const float init = CLEAR ? 0.0f : -__builtin_inff();
-    vfloat4 vinit = vfloat4{init, init, init, init};
-    asm volatile("" : "+v"(vinit));   // one register quad for all inlined copies of the tile set-up (see small_body)
-    StripBatch next;
-    fetch(reach(gbox, sy0, min(sy0 + TH, p.H)), next);
-#pragma unroll 1
-    for (int q = 0; q < TPS; ++q) {
-        t.ty0 = sy0 + q * TH;
-        if (t.ty0 >= p.H) break;
-        t.ty1 = min(t.ty0 + TH, p.H);
-        const StripBatch cur = next;
-        // tile q + 1: its candidates are requested now, i.e. before this tile's stores
-        if (TPS > 1 && q + 1 < TPS && t.ty1 < p.H) fetch(reach(gbox, t.ty1, min(t.ty1 + TH, p.H)), next);
-
-        bool tile_ready = false;
-        auto process_round = [&](int sub_base, const Cand& cand) {
-            const unsigned long long m = cull_test(t, sub_base, lane, cand);
-            if (m == 0) return;
-            if (!tile_ready) {
-                tile_ready = true;
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) *reinterpret_cast<vfloat4*>(&s_tile[row0 + i][(lane & 31) * 4]) = vinit;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // tile initialised before the first atomic
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            splat_round<false>(p, t, lane, m, cand, s_hit, s_tile);
-        };
-#pragma unroll
-        for (int u = 0; u < kStripFetch; ++u)
-            if (cur.sub_base[u] >= 0) process_round(cur.sub_base[u], cur.cand[u]);
-        // rare: more than kStripFetch groups of the first round reach this tile, or the plane has more than 64 groups
-        for (unsigned long long mg = cur.rest; mg;) {
-            StripBatch more;
-            fetch(mg, more);
-            mg = more.rest;
-#pragma unroll
-            for (int u = 0; u < kStripFetch; ++u)
-                if (more.sub_base[u] >= 0) process_round(more.sub_base[u], more.cand[u]);
-        }
-        for (int g0 = kCand; g0 < p.n_groups; g0 += kCand) {
-            for (unsigned long long mg = reach(load_group_box(p, t, g0 + lane), t.ty0, t.ty1); mg; mg &= mg - 1) {
-                const int sub_base = (g0 + __builtin_ctzll(mg)) * kCand;
-                process_round(sub_base, load_group_candidates(t, sub_base, lane));
-            }
-        }
-
-        if (!tile_ready) {
-            if constexpr (CLEAR) zero_rows(t.ty0, t.ty1);
-            continue;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // all atomics landed before the tile is read back
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (col0 < p.W) write_back_rows<CLEAR, SM, RPW>(p, t, plane_ptr, s_tile, row0, lane, col0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile re-initialises the LDS tile behind these reads
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
-// lane rasters of all scales in one launch of 256-thread workgroups: float sample points, two-level cull, scale from the
-// workgroup prefix.  Per scale (chosen on the host): COARSE — a tile is crossed by several lanes and has many sample groups
-// to walk, the four waves share ONE tile (small_body, NW = 4); FINE — the four waves own four neighbouring strips of
-// 1, 2 or 4 vertically consecutive tiles and never meet.  Both carve the same 4 x 9.25 KB of LDS.
-template <bool CLEAR, int SM>
-__global__ __launch_bounds__(256) void splat_points_multi_kernel(const MultiParams mp)
-{
-    constexpr int kWaveLds = kSmallTileBytes + kCand * (int)sizeof(Hit);   // tile + 1 KB hit list
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kWaveLds];
-    long long u = blockIdx.x;
-    if (mp.mix_shift > 0 && u < (mp.mix_units << mp.mix_shift)) {
-        const long long g = u >> mp.mix_shift, r = u & ((1ll << mp.mix_shift) - 1);
-        u = r == 0 ? g : mp.mix_units + g * ((1ll << mp.mix_shift) - 1) + (r - 1);
-    }
-    int s = 0;
-    while (s + 1 < mp.n_scales && u >= mp.tile_begin[s + 1]) ++s;
-    const long long unit = u - mp.tile_begin[s];
-    const int tps = mp.scale[s].strip_mode;
-    if (tps) {
-        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-        unsigned char* mine = lds + wave * kWaveLds;
-        Hit* hits = reinterpret_cast<Hit*>(mine + kSmallTileBytes);
-        if (tps == 1)
-            strip_body<CLEAR, SM, 1>(mp.scale[s], unit * 4 + wave, hits, reinterpret_cast<SmallTile>(mine));
-        else if (tps == 2)
-            strip_body<CLEAR, SM, 2>(mp.scale[s], unit * 4 + wave, hits, reinterpret_cast<SmallTile>(mine));
-        else
-            strip_body<CLEAR, SM, 4>(mp.scale[s], unit * 4 + wave, hits, reinterpret_cast<SmallTile>(mine));
-    } else {
-        small_body<CLEAR, SM, 2, 4>(mp.scale[s], unit, reinterpret_cast<Hit(*)[kCand]>(lds + kSmallTileBytes),
-                                    reinterpret_cast<SmallTile>(lds));
-    }
+    while (s + 1 < mp.n_scales && (long long)blockIdx.x >= mp.tile_begin[s + 1]) ++s;
+    small_body<CLEAR, SM, 2, NW>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s], s_hit, s_tile);
 }
 
 // bounding box (xmin, ymin, xmax, ymax) of every 64 consecutive points of points[b, :, :] (NaN points ignored; a group
@@ -1595,36 +1368,7 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
     mp.tile_begin[used] = tiles;
     if (used == 0 || tiles == 0) return ACCV_OK;
     if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: %lld tiles exceed the grid limit", tiles);
-    // per scale: a tile of a COARSE scale is crossed by several lanes and has many sample groups to walk — its four waves
-    // share the tile (>= 24 samples per tile on average; config 3: 7.5 / 30 / 113 at strides 4 / 8 / 16); a FINE scale is
-    // mostly empty tiles — strip mode, one wave per strip of tiles, four strips per workgroup
-    for (int i = 0; i < used; ++i) {
-        SplatParams& p = mp.scale[i];
-        bool coarse = (double)batch * num_points >= 24.0 * (double)p.n_tiles;
-        int tps = 1;
-        if (const int mode = accv::tune_get("pts_mode", -1); mode >= 0) coarse = mode == 0;   // A/B build only
-        if (const int k = accv::tune_get("pts_tps", -1); k == 1 || k == 2 || k == 4) tps = k;
-        p.strip_mode = coarse ? 0 : tps;
-        p.strips_y = (p.tiles_y + tps - 1) / tps;
-        p.n_strips = (long long)batch * p.strips_y * p.tiles_x;
-        p.n_units = coarse ? p.n_tiles : (p.n_strips + 3) / 4;
-    }
     if (!(flags & ACCV_HM_CALLER_SCALE_ORDER)) coarse_scales_first(mp);
-    long long units = 0;
-    for (int i = 0; i < used; ++i) {
-        mp.tile_begin[i] = units;
-        units += mp.scale[i].n_units;
-    }
-    mp.tile_begin[used] = units;
-    {   // interleave: coarse units (they come first) one per 2^shift workgroups while enough fine units remain to fill the gaps
-        long long coarse_units = 0;
-        for (int i = 0; i < used; ++i)
-            if (!mp.scale[i].strip_mode && mp.tile_begin[i] == coarse_units) coarse_units += mp.scale[i].n_units;
-        int shift = accv::tune_get("pts_mix", 0);
-        while (shift > 0 && (coarse_units << shift) > units) --shift;   // bijection needs (2^shift - 1) * coarse <= the rest
-        mp.mix_units = coarse_units;
-        mp.mix_shift = (coarse_units > 0 && coarse_units < units) ? shift : 0;
-    }
     const long long total_groups = (long long)batch * n_groups;
     if (total_groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: too many point groups");
     if (total_groups > 0 && !(flags & ACCV_HM_GROUP_BOXES_GIVEN))
@@ -1633,68 +1377,34 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
                            static_cast<float4*>(workspace));
     int nt = accv::tune_get("hm_nt", -1);
     if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;
-    if (accv::tune_get("pts_kernel", 0) == 0) {
-        // one tile per workgroup: four waves share a tile when some scale is coarse, else one wave per tile
-        bool heavy = false;
-        long long tiles = 0, coarse_tiles = 0;
-        for (int i = 0; i < used; ++i) {
-            heavy = heavy || mp.scale[i].strip_mode == 0;
-            if (mp.scale[i].strip_mode == 0 && coarse_tiles == tiles) coarse_tiles += mp.scale[i].n_tiles;
-            mp.scale[i].strip_mode = 0;
-            mp.tile_begin[i] = tiles;
-            tiles += mp.scale[i].n_tiles;
-        }
-        mp.tile_begin[used] = tiles;
-        {
-            int shift = accv::tune_get("pts_mix", 0);
-            while (shift > 0 && (coarse_tiles << shift) > tiles) --shift;
-            mp.mix_units = coarse_tiles;
-            mp.mix_shift = (coarse_tiles > 0 && coarse_tiles < tiles) ? shift : 0;
-        }
-        if (const int nw = accv::tune_get("pts_nw", -1); nw > 0) heavy = nw == 4;   // A/B build only
-        const dim3 grid((unsigned)tiles), block(heavy ? 256 : 64);
-#define ACCV_LAUNCH_POINTS(CL, SMV)                                                                  \
-    do {                                                                                             \
-        if (heavy)                                                                                   \
-            hipLaunchKernelGGL((splat_points_tile_kernel<CL, SMV, 4>), grid, block, 0, stream, mp);  \
-        else                                                                                         \
-            hipLaunchKernelGGL((splat_points_tile_kernel<CL, SMV, 1>), grid, block, 0, stream, mp);  \
+    // a tile of a coarse scale is crossed by several lanes and has many sample groups to walk: share it among four waves
+    // when some scale averages >= 24 samples per tile (config 3: 7.5 / 30 / 113 at strides 4 / 8 / 16); fine scales alone
+    // keep one wave per tile (mostly empty tiles would only pay the barriers: 21.7 -> 23.8 us at stride 4)
+    bool heavy = false;
+    for (int i = 0; i < used; ++i)
+        heavy = heavy || (double)batch * num_points >= 24.0 * (double)mp.scale[i].n_tiles;
+    if (const int nw = accv::tune_get("pts_nw", -1); nw > 0) heavy = nw == 4;   // A/B build only
+    const dim3 grid((unsigned)tiles), block(heavy ? 256 : 64);
+#define ACCV_LAUNCH_POINTS(CL, SMV)                                                                       \
+    do {                                                                                                  \
+        if (heavy)                                                                                        \
+            hipLaunchKernelGGL((splat_points_multi_kernel<CL, SMV, 4>), grid, block, 0, stream, mp);      \
+        else                                                                                              \
+            hipLaunchKernelGGL((splat_points_multi_kernel<CL, SMV, 1>), grid, block, 0, stream, mp);      \
     } while (0)
-        if (clear) {
-            if (nt >= 2)
-                ACCV_LAUNCH_POINTS(true, 4);
-            else
-                ACCV_LAUNCH_POINTS(true, 0);
-        } else {
-            if (nt >= 2)
-                ACCV_LAUNCH_POINTS(false, 4);
-            else
-                ACCV_LAUNCH_POINTS(false, 0);
-        }
-#undef ACCV_LAUNCH_POINTS
-        note_dispatch("splat_points_tile_kernel", 4, 8, clear, nt >= 2 ? 4 : 0, grid, block);
-        return accv::check_launch("draw_heatmap multi-scale point splat kernel");
-    }
-    const dim3 grid((unsigned)units), block(256);
     if (clear) {
         if (nt >= 2)
-            hipLaunchKernelGGL((splat_points_multi_kernel<true, 4>), grid, block, 0, stream, mp);
+            ACCV_LAUNCH_POINTS(true, 4);
         else
-            hipLaunchKernelGGL((splat_points_multi_kernel<true, 0>), grid, block, 0, stream, mp);
+            ACCV_LAUNCH_POINTS(true, 0);
     } else {
         if (nt >= 2)
-            hipLaunchKernelGGL((splat_points_multi_kernel<false, 4>), grid, block, 0, stream, mp);
+            ACCV_LAUNCH_POINTS(false, 4);
         else
-            hipLaunchKernelGGL((splat_points_multi_kernel<false, 0>), grid, block, 0, stream, mp);
+            ACCV_LAUNCH_POINTS(false, 0);
     }
+#undef ACCV_LAUNCH_POINTS
     note_dispatch("splat_points_multi_kernel", 4, 8, clear, nt >= 2 ? 4 : 0, grid, block);
-    {   // which scales (in launch order) run strip mode ('s') and which share a tile among four waves ('t')
-        char modes[kMaxScales + 1] = {0};
-        for (int i = 0; i < used; ++i) modes[i] = mp.scale[i].strip_mode ? 's' : 't';   // ('s': strip_mode tiles per wave)
-        char* buf = accv::dispatch_buffer();
-        const size_t len = strlen(buf);
-        snprintf(buf + len, 256 - len, " scale_modes(%s)", modes);
-    }
     return accv::check_launch("draw_heatmap multi-scale point splat kernel");
 }
 

@@ -81,10 +81,7 @@ def main():
     if "--sweep" in sys.argv:
         # A/B build only (make -C accv-lab_amd/csrc tune; ACCV_HIP_LIB=.../libaccv_hip_tune.so): per-scale mode of the point splat
         none_ = torch.zeros(B, dtype=torch.int32, device=dev)
-        for name, knobs in (("tile kernel, scales one after the other (coarse first)", {"pts_kernel": 0, "pts_mix": 0}),
-                            ("tile kernel, a coarse tile every 2nd workgroup", {"pts_kernel": 0, "pts_mix": 1}),
-                            ("tile kernel, a coarse tile every 4th workgroup", {"pts_kernel": 0, "pts_mix": 2}),
-                            ("unified kernel (coarse: 4 waves per tile, fine: wave per tile)", {"pts_kernel": 1, "pts_mode": -1, "pts_tps": 1, "pts_mix": 0})):
+        for name, knobs in (("default", {"pts_nw": -1}), ("one wave per tile", {"pts_nw": 1}), ("four waves per tile", {"pts_nw": 4})):
             for k, v in knobs.items():
                 nat.tune_set(k, v)
             row = {"mode": name}

@@ -179,9 +179,8 @@ def test_sampler_group_boxes_match_the_samples(q):
 
 
 def test_lane_splat_one_and_four_waves_per_tile_agree():
-    """splat_points_multi_kernel runs a FINE scale (few samples per tile) in strip mode — one wave per four vertically
-    consecutive tiles — and a COARSE one with four waves sharing a tile, both inside one launch; either must equal the
-    per-scale operator bit for bit"""
+    """splat_points_multi_kernel runs with one wave per tile when every scale is fine (few samples per tile) and with four
+    waves sharing a tile when some scale is coarse; both must equal the per-scale operator bit for bit"""
     from accvlab import _amd_native as nat
     from accvlab.draw_heatmap import draw_polylines_batched, draw_polylines_multiscale
 
@@ -195,11 +194,9 @@ def test_lane_splat_one_and_four_waves_per_tile_agree():
             base = [torch.rand(s_, generator=torch.Generator().manual_seed(7)).mul_(0.2).to(dev) for s_ in shapes]
             fused = [b.clone() for b in base]
             draw_polylines_multiscale(fused, pts_d, 128, 2, strides, 6.0, 0.8, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
-            d = nat.last_dispatch()
-            assert "block(256)" in d and "scale_modes(" in d
-            seen.update(d.split("scale_modes(")[1].split(")")[0])
+            seen.add("block(256)" in nat.last_dispatch())
             for i, s in enumerate(strides):
                 ref = base[i].clone()
                 draw_polylines_batched(ref, pts_d, 128, 2, s, 6.0, 0.8, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
                 assert torch.equal(fused[i], ref), (strides, s, clear)
-    assert seen == {"s", "t"}, "both per-scale modes must have been exercised"
+    assert seen == {True, False}, "both launch shapes must have been exercised"
