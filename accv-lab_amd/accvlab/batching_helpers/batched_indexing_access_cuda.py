@@ -36,6 +36,8 @@ def _native():
         addr = lambda name: ctypes.cast(getattr(h, name), ctypes.c_void_p).value  # noqa: E731
         _bh.bind_native(addr("accv_ragged_gather"), addr("accv_ragged_scatter"), addr("accv_ragged_gather_fill"),
                         addr("accv_last_error"))
+        if hasattr(_bh, "bind_mask_to_indices"):
+            _bh.bind_mask_to_indices(addr("accv_ragged_mask_to_indices_ws"), addr("accv_ragged_mask_to_indices_workspace_bytes"))
         _native_bound = True
     return _bh
 
@@ -413,6 +415,11 @@ def mask_to_indices(mask: torch.Tensor, valid_counts: Optional[torch.Tensor] = N
     """(extension, no reference counterpart in the native layer) positions of the True entries of every row
     of a 2-D mask, in order, as int64 ``[B, M]`` zero-filled behind, plus int64 counts ``[B]`` — the
     wave-ballot compaction that replaces torch boolean indexing in batched_bool_indexing."""
+    nat = _native()
+    if nat is not None and hasattr(nat, "mask_to_indices") and mask.dtype == torch.bool:
+        res = nat.mask_to_indices(mask, valid_counts)      # checks + allocations + launch in C++; None = declined
+        if res is not None:
+            return res
     if not (mask.is_cuda):
         raise RuntimeError("mask must be a CUDA tensor")
     if not (mask.dim() == 2):
@@ -432,7 +439,7 @@ def mask_to_indices(mask: torch.Tensor, valid_counts: Optional[torch.Tensor] = N
         lib = _nat.lib()
         with _nat.device_guard(m.device):
             # few, very wide rows take the segmented two-pass kernels, which need a few KB of workspace
-            ws_bytes = lib.accv_ragged_mask_to_indices_workspace_bytes(b, w) if w >= 8192 else 0
+            ws_bytes = lib.accv_ragged_mask_to_indices_workspace_bytes(b, w) if w >= 8192 else 0   # (0 below 2 segments)
             if ws_bytes:
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=m.device)
                 _call(lib.accv_ragged_mask_to_indices_ws(m.data_ptr(), vc_ptr, vc64, b, w, idx.data_ptr(), sizes.data_ptr(),

@@ -18,6 +18,7 @@
 //   * out-of-range indices are skipped and counted in an optional error counter instead of a device assert.
 #include <hip/hip_runtime.h>
 
+
 #include <cstdint>
 
 #include "accv_common.h"
@@ -396,6 +397,74 @@ __global__ __launch_bounds__(256) void mask_seg_write_kernel(const uint8_t* __re
     if (seg == 0 && tid == 0) out_sizes[row] = total;
 }
 
+// ---- the same in ONE launch (round 3) for rows of up to kOnePassSegs segments: every segment workgroup counts the hits
+// of its WHOLE row itself — up to three extra 4 KB mask reads that hit L2 — which yields both the hits in front of its
+// segment and the row total (the zero tail needs it) with no second launch and no workspace: 1 x 8192 5.7 -> 3.4 us.  Longer
+// rows keep the count launch + write launch: kernel-level they already take 6.2-6.7 us for 8 x 65 536 / 2 x 131 072 (two
+// tiny back-to-back launches overlap their launch cost), the redundant counting 8.5 / 12.7 us, and segment workgroups that
+// exchange their counts through tagged workspace words in one launch 14.3 us — a cross-workgroup round trip costs as much
+// as the launch it saves (profiles/r03_tails_probe_*.log).  What the 12.5 us of round 2 measured was the python operator.
+constexpr int kOnePassSegs = 4;
+
+__global__ __launch_bounds__(256) void mask_seg_onepass_kernel(const uint8_t* __restrict__ mask, const void* __restrict__ valid,
+                                                               int valid_i64, long long width, int segs, int vec,
+                                                               long long* __restrict__ out_idx, long long* __restrict__ out_sizes)
+{
+    __shared__ int s_w[4], s_before[4], s_total[4];
+    const long long row = blockIdx.y;
+    const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long limit = width;
+    if (valid) limit = max(0ll, min(width, load_int(valid, row, valid_i64)));
+    const uint8_t* mrow = mask + row * width;
+    unsigned bits = 0;
+    int before = 0, total = 0;
+#pragma unroll 4
+    for (int s2 = 0; s2 < segs; ++s2) {
+        const long long j = (long long)s2 * kSeg + (long long)tid * 16;
+        const unsigned b2 = j < limit ? nonzero_bytes16(mrow, j, limit, vec != 0) : 0u;
+        const int c2 = __popc(b2);
+        total += c2;
+        if (s2 < seg) before += c2;
+        if (s2 == seg) bits = b2;
+    }
+    const int c = __popc(bits);
+    int incl = c;  // inclusive scan of this segment's hits inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        before += __shfl_xor(before, d);
+        total += __shfl_xor(total, d);
+    }
+    if (lane == 63) s_w[wave] = incl;
+    if (lane == 0) {
+        s_before[wave] = before;
+        s_total[wave] = total;
+    }
+    __syncthreads();
+    int wave_before = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) wave_before += s_w[w];
+    const long long base = (long long)s_before[0] + s_before[1] + s_before[2] + s_before[3];
+    const long long row_total = (long long)s_total[0] + s_total[1] + s_total[2] + s_total[3];
+    long long* o = out_idx + row * width;
+    const long long j0 = (long long)seg * kSeg + (long long)tid * 16;
+    long long pos = base + wave_before + (incl - c);
+    while (bits) {  // this thread's hits, in order
+        const int k = __builtin_ctz(bits);
+        bits &= bits - 1;
+        o[pos++] = j0 + k;
+    }
+    // zero tail of the row: positions [total, width) that fall into this segment's position range
+    const long long z0 = max(row_total, (long long)seg * kSeg), z1 = min(width, (long long)(seg + 1) * kSeg);
+    for (long long j = z0 + tid; j < z1; j += 256) o[j] = 0;
+    if (seg == 0 && tid == 0) out_sizes[row] = row_total;
+}
+
 // ---- flat -> padded pack: dst[i, j, :] = flat[offsets[i] + j, :] (j < sizes[i]); padding gets `pattern`
 // wide rows: one WORKGROUP of NW waves per row, NW*64 mask bytes per step; the waves' hit counts meet in LDS (double
 // buffered: one barrier per step) so that the order-preserving offsets stay exact
@@ -675,6 +744,13 @@ int accv_ragged_mask_to_indices_ws(const void* mask_u8, const void* valid_counts
         return accv::fail(ACCV_EINVAL, "ragged_mask_to_indices: null pointer");
     const uint8_t* m = static_cast<const uint8_t*>(mask_u8);
     const size_t need = accv_ragged_mask_to_indices_workspace_bytes(batch, width);
+    if (need > 0 && (width + kSeg - 1) / kSeg <= kOnePassSegs) {   // few segments per row: one launch, no workspace
+        const int segs = (int)((width + kSeg - 1) / kSeg);
+        const int vec = ((reinterpret_cast<uintptr_t>(m) & 15u) == 0 && width % 16 == 0) ? 1 : 0;
+        hipLaunchKernelGGL(mask_seg_onepass_kernel, dim3((unsigned)segs, (unsigned)batch), dim3(256), 0, stream, m,
+                           valid_counts_or_null, valid_i64, width, segs, vec, out_indices, out_sizes);
+        return accv::check_launch("ragged_mask_to_indices (segmented, one pass)");
+    }
     if (need > 0 && workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 3u) == 0) {
         const int segs = (int)((width + kSeg - 1) / kSeg);
         const int vec = ((reinterpret_cast<uintptr_t>(m) & 15u) == 0 && width % 16 == 0) ? 1 : 0;

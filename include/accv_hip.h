@@ -197,8 +197,9 @@ int accv_ragged_mask_to_indices(const void* mask_u8, const void* valid_counts_or
                                 long long width, long long* out_indices, long long* out_sizes, void* stream);
 /* The same with a caller-provided workspace of accv_ragged_mask_to_indices_workspace_bytes(batch, width) bytes (0 = not
  * needed): FEW, VERY WIDE rows (a dense anchor mask of a small batch) are cut into 4096-byte segments handled by one
- * workgroup each (count pass + write pass) instead of one workgroup per row.  Same results; without (enough) workspace
- * the one-workgroup-per-row kernels run. */
+ * workgroup each instead of one workgroup per row — in ONE launch for rows of up to 4 segments (every segment workgroup
+ * counts its whole row itself; the workspace is not touched), in a count launch + a write launch through the workspace
+ * beyond that.  Same results; without (enough) workspace the one-workgroup-per-row kernels run for the longer rows. */
 size_t accv_ragged_mask_to_indices_workspace_bytes(long long batch, long long width);
 int accv_ragged_mask_to_indices_ws(const void* mask_u8, const void* valid_counts_or_null, int valid_i64, long long batch,
                                    long long width, long long* out_indices, long long* out_sizes, void* workspace,

@@ -200,3 +200,32 @@ def test_split_uses_the_host_copy_of_the_sizes_and_detects_edits():
         edited = rb.split()
         assert [p.shape[0] for p in edited] == [min(1, t.shape[0]) for t in samples]
     assert ragged.host_sizes(torch.tensor([3, 1, 2])) == [3, 1, 2]
+
+
+@pytest.mark.gpu
+def test_native_mask_to_indices_agrees_with_the_python_formulation_and_declines_unusual_inputs():
+    """mask_to_indices: checks + the three allocations + the launch in C++ (csrc_host/bh_host.cpp) — same tensors as the python
+    formulation over the same C-ABI entry point; anything unusual is declined and diagnosed by the python code"""
+    from accvlab import _amd_native as nat
+    from accvlab.batching_helpers import batched_indexing_access_cuda as ext
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    for b, w, ragged in ((3, 40, False), (5, 700, True), (2, 5000, False), (8, 65536, True), (1, 8192, False)):
+        mask = (torch.rand(b, w, generator=g) < 0.3).to(dev)
+        valid = torch.randint(0, w + 1, (b,), generator=g).to(dev) if ragged else None
+        got = ext.mask_to_indices(mask, valid)
+        saved = nat.NO_HOST_FASTPATH
+        nat.NO_HOST_FASTPATH = True
+        try:
+            want = ext.mask_to_indices(mask, valid)
+        finally:
+            nat.NO_HOST_FASTPATH = saved
+        assert got[0].dtype == torch.int64 and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # declined -> python path: non-bool masks are converted, wrong ranks / devices raise the usual errors
+    idx, sizes = ext.mask_to_indices((torch.arange(12, device=dev).reshape(3, 4) % 3).to(torch.int32))
+    assert sizes.tolist() == [2, 3, 3]
+    with pytest.raises(RuntimeError):
+        ext.mask_to_indices(torch.ones(4, dtype=torch.bool, device=dev))
+    with pytest.raises(RuntimeError):
+        ext.mask_to_indices(torch.ones(2, 4, dtype=torch.bool))

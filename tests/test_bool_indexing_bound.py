@@ -97,3 +97,51 @@ def test_mask_to_indices_all_kernel_variants(b, m, ragged):
         want = torch.nonzero(row).flatten()
         assert int(sizes[i]) == want.numel()
         assert torch.equal(idx[i, :want.numel()], want) and bool((idx[i, want.numel():] == 0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,m,density", [(8, 65536, 0.1), (2, 262144, 0.5), (1, 8192, 0.0), (4, 12288, 1.0), (3, 16384, 0.4), (16, 70001, 0.03),
+                                         (64, 65536, 0.2), (1, 1048576, 0.01)])
+def test_segmented_mask_to_indices_one_pass_two_pass_and_graph_replay(b, m, density):
+    """few, very wide rows: ONE launch
+    for rows of up to 4 segments (every segment workgroup counts its whole row itself), two launches beyond — same indices,
+    call after call, and from a replayed graph"""
+    from accvlab.batching_helpers import batched_indexing_access_cuda as ext
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(b * 7 + m)
+
+    def want(mask, valid):
+        out = torch.zeros(mask.shape, dtype=torch.int64)
+        sizes = torch.zeros(mask.shape[0], dtype=torch.int64)
+        for i in range(mask.shape[0]):
+            row = mask[i].clone()
+            if valid is not None:
+                row[int(valid[i]):] = False
+            nz = torch.nonzero(row).flatten()
+            out[i, :nz.numel()] = nz
+            sizes[i] = nz.numel()
+        return out, sizes
+
+    for rep in range(3):     # repeated calls recycle the allocator's workspace block: stale words of older tags must not count
+        mask = torch.rand(b, m, generator=g) < density
+        valid = torch.randint(0, m + 1, (b,), generator=g) if rep == 1 else None
+        idx, sizes = ext.mask_to_indices(mask.to(dev), valid.to(dev) if valid is not None else None)
+        w_idx, w_sizes = want(mask, valid)
+        assert torch.equal(sizes.cpu(), w_sizes) and torch.equal(idx.cpu(), w_idx)
+    # captured: the launch(es) must be replayable with new mask contents (the tagged one-pass path is not taken there)
+    static = (torch.rand(b, m, generator=g) < density).to(dev)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ext.mask_to_indices(static)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_idx, g_sizes = ext.mask_to_indices(static)
+    for _ in range(2):
+        fresh = torch.rand(b, m, generator=g) < max(density, 0.05)
+        static.copy_(fresh.to(dev))
+        graph.replay()
+        torch.cuda.synchronize()
+        w_idx, w_sizes = want(fresh, None)
+        assert torch.equal(g_sizes.cpu(), w_sizes) and torch.equal(g_idx.cpu(), w_idx)
