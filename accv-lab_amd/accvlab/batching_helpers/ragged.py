@@ -34,8 +34,11 @@ except ImportError:  # pragma: no cover
 
 def remember_host_sizes(sizes: torch.Tensor, values) -> torch.Tensor:
     """Attach the host copy of a DEVICE sample-size tensor to it (row-major python ints) so that consumers which need the
-    sizes on the host (``split``) do not have to read them back — a device synchronisation.  The copy is trusted only while
-    the tensor's version counter is unchanged, so any in-place edit of the tensor invalidates it."""
+    sizes on the host (``split``) do not have to read them back — a device synchronisation.  Only ``combine_data`` does this,
+    for size tensors it has just made FROM host values.  The copy is trusted while the tensor's version counter is unchanged,
+    so any in-place edit through autograd-visible operations invalidates it.  Writes the version counter does not see —
+    ``sizes.data.copy_(...)``, ``set_()``, a kernel that writes through ``data_ptr()``, a graph replay that refills the
+    buffer — do not: code that rewrites such a tensor must call :func:`forget_host_sizes` (or build a new RaggedBatch)."""
     try:
         sizes._accv_host_sizes = (list(values), sizes._version)
     except Exception:  # pragma: no cover - tensor subclasses without a __dict__
@@ -43,15 +46,25 @@ def remember_host_sizes(sizes: torch.Tensor, values) -> torch.Tensor:
     return sizes
 
 
+def forget_host_sizes(sizes: torch.Tensor) -> torch.Tensor:
+    """Drop the host copy attached by ``combine_data`` (see :func:`remember_host_sizes`): the next ``split()`` reads the device
+    tensor again."""
+    try:
+        del sizes._accv_host_sizes
+    except AttributeError:
+        pass
+    return sizes
+
+
 def host_sizes(sizes: torch.Tensor) -> list:
-    """Row-major python ints of ``sizes``; from the attached host copy when it is still valid, else one read-back."""
+    """Row-major python ints of ``sizes``; from the host copy ``combine_data`` attached while it is still valid, else ONE
+    read-back (which is not cached: a tensor that was read from the device once may be rewritten behind the version
+    counter's back, e.g. by a graph replay, and must be read again)."""
     hit = getattr(sizes, "_accv_host_sizes", None)
     if hit is not None and hit[1] == sizes._version and len(hit[0]) == sizes.numel():
-        return hit[0]
-    values = sizes.reshape(-1).tolist()
-    if sizes.is_cuda:
-        remember_host_sizes(sizes, values)
-    return values
+        if not (sizes.is_cuda and torch.cuda.is_current_stream_capturing()):
+            return hit[0]
+    return sizes.reshape(-1).tolist()
 
 
 class RaggedBatch:

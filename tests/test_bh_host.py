@@ -229,3 +229,26 @@ def test_native_mask_to_indices_agrees_with_the_python_formulation_and_declines_
         ext.mask_to_indices(torch.ones(4, dtype=torch.bool, device=dev))
     with pytest.raises(RuntimeError):
         ext.mask_to_indices(torch.ones(2, 4, dtype=torch.bool))
+
+
+@pytest.mark.gpu
+def test_sizes_rewritten_behind_the_version_counter():
+    """a device size tensor that was merely READ once is read again by every split() (the read-back is not cached —
+    `.data` writes, raw-pointer kernels and graph replays do not bump the version counter); a combine_data size tensor
+    that is rewritten that way needs forget_host_sizes()"""
+    from accvlab.batching_helpers import RaggedBatch, ragged
+
+    dev = torch.device("cuda", 0)
+    data = torch.arange(24.0, device=dev).reshape(3, 4, 2)
+    sizes = torch.tensor([4, 2, 3], device=dev)
+    rb = RaggedBatch(data, sample_sizes=sizes)
+    assert [p.shape[0] for p in rb.split()] == [4, 2, 3]
+    assert getattr(sizes, "_accv_host_sizes", None) is None          # nothing cached from a read-back
+    sizes.data.copy_(torch.tensor([1, 0, 2], device=dev))            # invisible to the version counter
+    assert [p.shape[0] for p in rb.split()] == [1, 0, 2]
+    # combine_data's host copy survives such a write (documented): the caller drops it explicitly
+    rb2 = combine_data([torch.rand(n, 2) for n in (3, 1, 2)], device=dev)
+    rb2.sample_sizes.data.copy_(torch.tensor([1, 1, 1], device=dev))
+    ragged.forget_host_sizes(rb2.sample_sizes)
+    assert [p.shape[0] for p in rb2.split()] == [1, 1, 1]
+    ragged.forget_host_sizes(rb2.sample_sizes)                       # idempotent

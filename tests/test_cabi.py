@@ -90,3 +90,57 @@ def test_null_pointer_sweep_is_rejected_or_empty(value):
         status = fn(*vals)
         allowed = (0, -1, -3, -2) if name == "accv_memcpy_async" else (0, -1, -3)
         assert status in allowed, f"{name}({value}): status {status}: {lib.accv_last_error()}"
+
+
+@pytest.mark.parametrize("value", [3, 0, -2])
+def test_every_trampoline_eligible_entry_point_behaves_like_its_ctypes_binding(value):
+    """the trampoline calls every entry point through one fixed 20-slot function type.  Each entry point it is
+    eligible for is therefore called through BOTH bindings with the same arguments (NULL pointers, one integer value, 1.5 /
+    2.5 for the floats): the status and the thread's error text must be identical — a mis-passed argument changes which
+    validation fires first.  (The GPU suite additionally runs once over ctypes alone: profiles/r03_gpu_tests_ctypes_binding.log.)"""
+    from accvlab import _amd_native as nat
+
+    assert nat._fastcall is not None, "build the host extensions (make -C accv-lab_amd/csrc_host)"
+    plain = nat.ctypes_lib()
+    checked = 0
+    for name, (res, args) in sorted(nat.SIGNATURES.items()):
+        if name in nat._BLOCKING or not args:
+            continue
+        fast = nat._fast_entry(getattr(plain, name), res, args)
+        if fast is None:
+            continue
+        floats = iter((1.5, 2.5))
+        vals = [None if a in (ctypes.c_void_p, ctypes.c_char_p) else next(floats) if a is ctypes.c_float else value for a in args]
+        s_fast, e_fast = fast(*vals), plain.accv_last_error()
+        s_plain, e_plain = getattr(plain, name)(*vals), plain.accv_last_error()
+        assert s_fast == s_plain, f"{name}({value}): trampoline {s_fast} vs ctypes {s_plain}"
+        assert s_fast == 0 or e_fast == e_plain, f"{name}({value}): {e_fast!r} vs {e_plain!r}"
+        checked += 1
+    assert checked >= 20, f"only {checked} entry points went through the trampoline"
+
+
+def test_trampoline_passes_values_and_pointers_like_ctypes():
+    """a call with real pointers, large and negative integers: the pack planner fills the same arrays through both bindings"""
+    import numpy as np
+
+    from accvlab import _amd_native as nat
+
+    plain = nat.ctypes_lib()
+    fast = nat._fast_entry(plain.accv_mtc_plan, *nat.SIGNATURES["accv_mtc_plan"])
+    assert fast is not None
+    rng = np.random.default_rng(0)
+    n = 300
+    nbytes = rng.integers(1, 5000, n).astype(np.int64)
+    esize = rng.choice([1, 2, 4, 8, 16], n).astype(np.int32)
+    cand = (rng.random(n) < 0.8).astype(np.uint8)
+    outs = []
+    for call in (fast, plain.accv_mtc_plan):
+        off, chk, csz = np.full(n, -9, np.int64), np.full(n, -9, np.int64), np.full(n, -9, np.int64)
+        k = ctypes.c_longlong(-1)
+        args = (n, nbytes.ctypes.data, esize.ctypes.data, cand.ctypes.data, 16, 1 << 40, off.ctypes.data, chk.ctypes.data,
+                csz.ctypes.data, ctypes.addressof(k))
+        assert call(*args) == 0
+        outs.append((off.copy(), chk.copy(), csz[:k.value].copy(), k.value))
+    assert outs[0][3] == outs[1][3] >= 1
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert np.array_equal(a, b)
