@@ -13,7 +13,7 @@
 //     (in-place mode, only tiles that are touched).
 //
 // Kernels in this file (all share locate_tile / cull_round / make_hit):
-//   splat_kernel        the tile kernel above = splat_body<PX,R,CLEAR,SM,WPG,SRC=0> (headline: <4,8,true,4,1>)
+//   splat_kernel        the tile kernel above = splat_body<PX,R,CLEAR,SM,WPG,SRC=0> (headline: <4,8,true,0,1>, in place <4,8,false,5,1>)
 //   splat_multi_kernel  the same body over the tiles of up to four scales in one launch, objects given as float
 //                       centres / boxes and converted per scale inside the cull (SRC=1)
 //   splat_small_kernel  point-like objects (ACCV_HM_SMALL_RADII): tile in LDS, lanes walk each hit's box, ds_max_f32

@@ -344,9 +344,55 @@ def f3():
                       "composition_fwd_us": t_cf * 1e6, "fused_fwd_us": t_ff * 1e6, "fwd_speedup": t_cf / t_ff,
                       "composition_fwd_bwd_us": t_cb * 1e6, "fused_fwd_bwd_us": t_fb * 1e6, "fwd_bwd_speedup": t_cb / t_fb,
                       "max_abs_difference": err}))
+    # round 3: the reference example's own per-object losses through the fused op — box overlap (1 - IoU) and L1 between
+    # one-hot labels and scores — against the composition the example writes (gathers + element-wise code + masked sum)
+    lab_t = labels.tensor.contiguous()
+
+    def comp_iou(pred):
+        ga = bh.batched_indexing_access(gt_boxes, m_gt)
+        gp = bh.batched_indexing_access(pred, m_pred)
+        gw_ = bh.batched_indexing_access(w_t, m_gt)
+        per_obj = (1.0 - ml._iou(ga.tensor, gp.tensor)) * gw_.tensor
+        return bh.sum_over_targets(ga.create_with_sample_sizes_like_self(per_obj, non_uniform_dim=1))
+
+    def fused_iou(pred):
+        return bh.matched_pair_loss_sum(gt_boxes, pred, m_gt, m_pred, w_t, kind="iou_xyxy", eps=ml.EPS)
+
+    def comp_cls(scores):
+        gl_ = bh.batched_indexing_access(lab_t, m_gt)
+        gs = bh.batched_indexing_access(scores, m_pred)
+        gw_ = bh.batched_indexing_access(w_t, m_gt)
+        per_obj = gw_.tensor * (gs.tensor - ml._one_hot(gl_.tensor.to(torch.int64), C)).abs().sum(-1)
+        return bh.sum_over_targets(gl_.create_with_sample_sizes_like_self(per_obj, non_uniform_dim=1))
+
+    def fused_cls(scores):
+        return bh.matched_pair_loss_sum(lab_t, scores, m_gt, m_pred, w_t, kind="onehot_l1")
+
+    def fb2(fn, x):
+        p = x.clone().requires_grad_(True)
+        fn(p).sum().backward()
+
+    for name, comp, fus, x in (("iou_xyxy", comp_iou, fused_iou, pb), ("onehot_l1", comp_cls, fused_cls, ps)):
+        with torch.no_grad():
+            err2 = float((comp(x) - fus(x)).abs().max())
+        print(json.dumps({"config": f"F3 fused kernel, kind {name}", "composition_fwd_us": _timeit(lambda: comp(x), 20, 200, sync) * 1e6,
+                          "fused_fwd_us": _timeit(lambda: fus(x), 20, 200, sync) * 1e6,
+                          "composition_fwd_bwd_us": _timeit(lambda: fb2(comp, x), 10, 100, sync) * 1e6,
+                          "fused_fwd_bwd_us": _timeit(lambda: fb2(fus, x), 10, 100, sync) * 1e6, "max_abs_difference": err2}))
+    for dt in (torch.float16, torch.bfloat16, torch.float64):
+        a16, p16, w16 = gt_boxes.to(dt), pb.to(dt), w_t.to(dt)
+        print(json.dumps({"config": f"F3 fused kernel, kind l1, {dt}",
+                          "fused_fwd_us": _timeit(lambda: bh.matched_pair_loss_sum(a16, p16, m_gt, m_pred, w16, kind="l1"), 20, 200, sync) * 1e6}))
+
+    def loss_only_fused():
+        leaves = [t.clone().requires_grad_(True) for t in (pb, ps, pe)]
+        ml.loss_batched_fused(boxes, labels, weights, *leaves, m_gt, m_pred).sum().backward()
+
+    t_lof = _timeit(loss_only_fused, 5, 50, sync)
     print(json.dumps({"config": "F3", "shape": {"batch": B, "queries": Q, "classes": C, "max_gt": G},
                       "batched_fwd_bwd_ms": t_b * 1e3, "per_sample_loop_fwd_bwd_ms": t_l * 1e3,
-                      "speedup": t_l / t_b, "batched_loss_only_fwd_bwd_ms": t_lo * 1e3}))
+                      "speedup": t_l / t_b, "batched_loss_only_fwd_bwd_ms": t_lo * 1e3,
+                      "batched_loss_only_fused_class_and_box_terms_fwd_bwd_ms": t_lof * 1e3}))
 
 
 class _MetaDataset(torch.utils.data.Dataset):

@@ -7,7 +7,7 @@
 # interpreter itself.  Output: gpurun_out/prof_final/{trace,write,fetch}/ + summary.json (scripts/summarise_profiles.py).
 set -euo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
-OUT="$ROOT/gpurun_out/prof_final"
+OUT="$ROOT/gpurun_out/r03/prof_final"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"

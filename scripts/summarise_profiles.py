@@ -20,8 +20,19 @@ def rows(pattern):
 def main(out):
     res = {}
     trace = rows(os.path.join(out, "trace", "**", "*kernel_trace.csv"))
-    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace
-           if "splat_kernel<" in r["Kernel_Name"] and "true" in r["Kernel_Name"].split("splat_kernel")[1][:20]]
+    # launches of the headline instantiation over the headline batch only: bench.py also draws shards of 8 / 16 / 32 frames
+    # (strong-scaling prediction) and the rule-B batch with the same kernel
+    frames = 64
+    try:
+        with open(os.path.join(out, "bench_under_rocprof.json")) as fh:
+            frames = json.loads([l for l in fh.read().splitlines() if l.startswith("{")][-1])["config"]["frames_per_gpu"]
+    except Exception:  # noqa: BLE001
+        pass
+    res["frames_per_launch"] = frames
+    trace = sorted(trace, key=lambda r: int(r["Start_Timestamp"]))
+    clear_all = [r for r in trace if "splat_kernel<" in r["Kernel_Name"] and "true" in r["Kernel_Name"].split("splat_kernel")[1][:20]]
+    dur_all = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in clear_all]
+    dur = [d for r, d in zip(clear_all, dur_all) if int(r.get("Grid_Size_Z", frames)) == frames]
     if dur:
         res["clear_kernel"] = {"name": next(r["Kernel_Name"] for r in trace if "splat_kernel" in r["Kernel_Name"]),
                                "launches": len(dur), "avg_us_all": sum(dur) / len(dur) / 1e3}
@@ -30,10 +41,11 @@ def main(out):
         try:
             with open(os.path.join(out, "bench_under_rocprof.json")) as fh:
                 idx = json.loads([l for l in fh.read().splitlines() if l.startswith("{")][-1])["roofline"]["trace_index"]
+            # (the indices count every fused clear+draw launch of the run in issue order: index into the unfiltered list)
             a, n = idx["timed_region_first_launch"], idx["timed_region_launches"]
-            res["clear_kernel"]["avg_us_timed_region_back_to_back"] = sum(dur[a:a + n]) / n / 1e3
+            res["clear_kernel"]["avg_us_timed_region_back_to_back"] = sum(dur_all[a:a + n]) / n / 1e3
             b, m = idx["spaced_first_launch"], idx["spaced_launches"]
-            res["clear_kernel"]["avg_us_spaced_launches"] = sum(dur[b:b + m]) / m / 1e3
+            res["clear_kernel"]["avg_us_spaced_launches"] = sum(dur_all[b:b + m]) / m / 1e3
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             res["clear_kernel"]["avg_us_last500"] = sum(dur[-500:]) / len(dur[-500:]) / 1e3
     stats = rows(os.path.join(out, "trace", "**", "*kernel_stats.csv"))
@@ -43,7 +55,10 @@ def main(out):
         cr = rows(os.path.join(out, sub, "**", "*counter_collection.csv"))
         per = {}
         for r in cr:
-            if r.get("Counter_Name") != counter or "splat_kernel" not in r["Kernel_Name"]:
+            if r.get("Counter_Name") != counter or "splat_kernel<" not in r["Kernel_Name"]:
+                continue
+            # Grid_Size = work-items of the launch: tiles_x * tiles_y * frames workgroups of 64 lanes (1920 x 1080: 15 x 68 tiles)
+            if int(float(r.get("Grid_Size", 0))) != 15 * 68 * frames * 64:
                 continue
             mode = "clear" if ", true," in r["Kernel_Name"] else "inplace"
             per.setdefault(mode, []).append(float(r["Counter_Value"]))
@@ -62,7 +77,7 @@ def main(out):
         with open(os.path.join(out, "bench_write.json")) as fh:
             bw = json.loads([l for l in fh.read().splitlines() if l.startswith("{")][-1])
         if "hbm_bytes_per_launch_clear" in res:
-            res["traffic_record"] = {"kernel": bw["roofline"]["kernel"].split(" grid")[0],
+            res["traffic_record"] = {"kernel": bw["roofline"]["kernel"].split(" grid")[0], "frames": frames,
                                      "hbm_bytes_per_launch": res["hbm_bytes_per_launch_clear"],
                                      "write_size_kb": w, "fetch_size_kb_raw": f,
                                      "method": "separate rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes over bench.py; "
