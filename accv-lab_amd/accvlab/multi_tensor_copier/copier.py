@@ -321,6 +321,27 @@ def _register_native_shutdown() -> None:
         _shutdown_registered = True
 
 
+def set_output_recycling(enabled: bool) -> None:
+    """(extension) Switch the re-use of output tensor objects between consecutive packed copies on (default) or off.
+
+    A result of N packed leaves is N tensor objects, and creating / destroying them is what a many-leaf copy costs
+    (≈ 300 ns per leaf; the transfer itself is microseconds).  The C++ host path therefore keeps the packed output tensors
+    of the last two calls and, when the next call has a packed leaf at the same position with the same dtype and device,
+    re-points a kept tensor object at its new place in the new chunk — but ONLY a tensor that nothing refers to any more
+    (no variable, container or view in python, nothing in C++).  Visible effects: such an object may come back with a
+    new content under the same ``id()`` (a ``weakref`` to an old output is not a reference), and the chunk storage of
+    up to two earlier results stays allocated (≤ 256 MB each) until the next call or :func:`release_cached_outputs`.
+    """
+    if _host is not None:
+        _host.set_output_recycling(bool(enabled))
+
+
+def release_cached_outputs() -> None:
+    """(extension) Drop the output tensors kept for re-use (see :func:`set_output_recycling`) and the chunk storage they pin."""
+    if _host is not None:
+        _host.release_recycled_outputs()
+
+
 def _run(job: _Job) -> None:
     """Orchestration (worker thread or inline): plan, allocate, stage, enqueue, build views."""
     lib = _nat.lib() if (job.device.type == "cuda" or job.meta[0].max(initial=0) > R_REUSE) else None

@@ -194,3 +194,68 @@ assert rc != 0 and b"shut down" in lib.accv_last_error()
 print("ok")
 ''')
     assert "ok" in out
+
+
+# ---- output recycling of the C++ host path (round 3): driven directly on CPU "chunks", no GPU involved
+def _views_of(host, tree_obj, chunk, offsets):
+    t = host.Tree(tree_obj)
+    n = t.num_leaves()
+    t.make_packed_views(np.arange(n, dtype=np.int64), np.zeros(n, dtype=np.int64), offsets, [chunk], np.zeros(1, dtype=np.int64))
+    return t.rebuild()
+
+
+def test_output_tensor_objects_are_recycled_only_when_nothing_refers_to_them():
+    import gc
+
+    from accvlab.multi_tensor_copier import copier
+
+    host = copier._host
+    assert host is not None, "build the host extensions (make -C accv-lab_amd/csrc_host)"
+    copier.release_cached_outputs()
+    copier.set_output_recycling(True)
+    leaves = [torch.zeros(4), torch.zeros(3, dtype=torch.int64), torch.zeros(2, 2)]
+    offsets = np.array([0, 16, 48], dtype=np.int64)
+
+    def result(fill):
+        chunk = torch.zeros(80, dtype=torch.uint8)
+        chunk[0:16] = torch.full((4,), float(fill)).view(torch.uint8)
+        chunk[16:40] = torch.full((3,), int(fill), dtype=torch.int64).view(torch.uint8)
+        chunk[48:64] = torch.full((4,), float(-fill)).view(torch.uint8)
+        return _views_of(host, {"a": leaves[0], "b": [leaves[1], leaves[2]]}, chunk, offsets)
+
+    r1 = result(1)
+    kept = r1["a"]                       # the caller keeps ONE tensor of the first result (and a view of another)
+    view = r1["b"][1][0]
+    ids1 = (id(r1["a"]), id(r1["b"][0]), id(r1["b"][1]))
+    del r1
+    r2 = result(2)
+    del r2
+    gc.collect()
+    r3 = result(3)                       # the tensors of result 1 that nobody holds may come back, re-pointed
+    assert r3["a"].tolist() == [3.0] * 4 and r3["b"][0].tolist() == [3] * 3 and r3["b"][1].tolist() == [[-3.0, -3.0], [-3.0, -3.0]]
+    assert kept.tolist() == [1.0] * 4, "a tensor the caller still holds was re-pointed"
+    assert view.tolist() == [-1.0, -1.0], "a view of an old output lost its base"
+    assert id(r3["a"]) != ids1[0] and id(r3["b"][1]) != ids1[2]          # held / viewed -> fresh objects
+    # steady state: the objects alternate between two generations, none is created or destroyed
+    seen = set()
+    for k in range(4, 12):
+        r = result(k)
+        assert r["a"].tolist() == [float(k)] * 4 and r["b"][0].tolist() == [k] * 3
+        seen.add((id(r["a"]), id(r["b"][0]), id(r["b"][1])))
+        del r
+    assert len(seen) <= 2, seen
+    # a different structure at the same positions: dtype mismatch -> fresh tensors, correct values
+    chunk = torch.arange(80, dtype=torch.uint8)
+    other = _views_of(host, [torch.zeros(16, dtype=torch.uint8), torch.zeros(6, dtype=torch.int32)], chunk, np.array([0, 16], dtype=np.int64))
+    assert other[0].dtype == torch.uint8 and other[0].tolist() == list(range(16)) and other[1].dtype == torch.int32
+    # switching it off / releasing empties the pool
+    assert host.recycled_output_count() > 0
+    copier.release_cached_outputs()
+    assert host.recycled_output_count() == 0
+    copier.set_output_recycling(False)
+    a = result(20)
+    ida = id(a["a"])
+    del a
+    b = result(21)
+    assert host.recycled_output_count() == 0 and b["a"].tolist() == [21.0] * 4
+    copier.set_output_recycling(True)

@@ -313,3 +313,42 @@ def test_background_mode_runs_on_the_native_orchestrator(n):
     h2 = mtc.start_copy(data + [torch.rand(500_000)], DEV, use_background_thread=True)
     assert h2._future is not None
     assert torch.equal(h2.get()[-1].cpu(), h2._job.tree.leaf(h2._job.tree.num_leaves() - 1))
+
+
+@pytest.mark.parametrize("background", [True, False])
+@pytest.mark.parametrize("direction", ["h2d", "d2h"])
+def test_repeated_copies_recycle_output_objects_without_touching_held_ones(background, direction):
+    """round 3: consecutive packed copies of the same structure re-point the output tensor objects nobody refers to any more
+    (the object life cycle is what a many-leaf copy costs); tensors the caller still holds keep their content, every result
+    has the right values, and the python twin of the host path (no recycling) agrees"""
+    from accvlab.multi_tensor_copier import copier, release_cached_outputs, start_copy
+
+    if copier._host is None:
+        pytest.skip("host extension not built")
+    release_cached_outputs()
+    src_dev, dst = ("cpu", DEV) if direction == "h2d" else (DEV, "cpu")
+    g = torch.Generator().manual_seed(3)
+
+    def batch(k):
+        return {"gt": [(torch.rand(5 + i, 4, generator=g) + k).to(src_dev) for i in range(6)],
+                "ids": tuple(torch.full((3 + i,), 100 * k + i, dtype=torch.int64).to(src_dev) for i in range(4)), "tag": f"b{k}"}
+
+    held, results = [], []
+    for k in range(8):
+        data = batch(k)
+        res = start_copy(data, dst, use_background_thread=background).get()
+        assert res["tag"] == f"b{k}"
+        for a, b in zip(res["gt"] + list(res["ids"]), data["gt"] + list(data["ids"])):
+            assert a.device.type == torch.device(dst).type and torch.equal(a.cpu(), b.cpu())
+        if k in (1, 4):
+            held.append((res["gt"][2], data["gt"][2].cpu().clone(), res["ids"][1][1:], data["ids"][1][1:].cpu().clone()))
+        results.append({id(t) for t in res["gt"]})
+        del res
+    for kept, want, view, want_view in held:          # held tensors (and views of outputs) were never re-pointed
+        assert torch.equal(kept.cpu(), want) and torch.equal(view.cpu(), want_view)
+    import os
+    if os.environ.get("ACCV_MTC_PY_HOST") != "1":      # (the python twin of the host path builds fresh tensors every time)
+        assert results[-1] & (results[-3] | results[-2]), "no output object was recycled in the steady state"
+        assert copier._host.recycled_output_count() > 0
+    release_cached_outputs()
+    assert copier._host.recycled_output_count() == 0
