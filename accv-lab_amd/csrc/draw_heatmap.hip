@@ -466,7 +466,9 @@ __global__ __launch_bounds__(64) void splat_multi_kernel(const MultiParams mp)
 // instructions each instead of one wave with eight.
 // ---- pieces of the per-tile body (small_body)
 constexpr int kSmallTW = 128, kSmallTH = 16;
-constexpr int kSmallLdsW = kSmallTW;
+// LDS row stride of the tile: 128 + 4 floats.  The row walk below puts consecutive ROWS of a splat on consecutive lanes; with a
+// stride of 128 floats they would all land on one LDS bank, with 132 they are 4 banks apart (16-byte row reads stay aligned)
+constexpr int kSmallLdsW = kSmallTW + 4;
 using SmallTile = float (*)[kSmallLdsW];
 
 // compaction of one cull round into the wave's hit list, then the hits' boxes are walked: four hits at a time, 16 lanes
@@ -475,24 +477,49 @@ using SmallTile = float (*)[kSmallLdsW];
 // (Round 3 measured a row-per-lane walk with padded LDS rows — 12 hits per pass instead of 4: -2 % on config 3, +6 % on
 // its stride-4 map alone, i.e. nothing: the launch is bound by the latency chains of its tiles, not by this loop;
 // profiles/r03_lane_splat_variants_walk_cull_vs_prev.log.)
+// rows_hint > 0: no clipped box of the list is taller than that (point splats: 2 r + 1) — then a lane takes ONE ROW of one hit
+// and runs along its columns (radius 2: 12 hits per pass, 5 updates per lane) instead of 16 lanes sharing a hit's box in
+// row-major order (4 hits per pass, 2 trips of ~15 dependent instructions for 25 pixels).  With one wave per tile the walk
+// is part of the tile's serial chain, and the tiles of a coarse scale carry dozens of hits (round 3)
 template <bool WG_SCOPE>
-__device__ __forceinline__ int splat_round(const SplatParams& p, const TileCtx& t, int lane, unsigned long long m, const Cand& cand,
-                                           Hit* __restrict__ hits, SmallTile tile)
+__device__ __forceinline__ void walk_hits(const SplatParams& p, const TileCtx& t, int lane, int nh, const Hit* __restrict__ hits,
+                                          SmallTile tile, int rows_hint)
 {
-    const int nh = __popcll(m);
-    if ((m >> lane) & 1ull) hits[__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, cand.x, cand.y, cand.r);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the hit list is complete
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {   // four hits at a time, 16 lanes per hit over its box in row-major order
+    if (rows_hint > 0 && rows_hint <= 16) {
+        const int per_pass = 64 / rows_hint;
+        const int hl = (int)((float)lane * (1.0f / (float)rows_hint) + 1e-3f);   // lane / rows_hint for lane < 64, rows <= 16
+        const int rl = lane - hl * rows_hint;
+        for (int h0 = 0; h0 < nh; h0 += per_pass) {
+            const int h = h0 + hl;
+            if (h >= nh || hl >= per_pass) continue;
+            const Hit hh = hits[h];
+            const int xlo = hh.box & 255u, xhi = (hh.box >> 8) & 255u, ylo = (hh.box >> 16) & 255u, yhi = hh.box >> 24;
+            const int py = ylo + rl;
+            if (py >= yhi) continue;
+            const float dy = (float)(t.ty0 + py - hh.y);
+            const float dy2 = dy * dy;
+            float* row = &tile[py][0];
+            for (int px = xlo; px < xhi; ++px) {
+                const float dx = (float)(t.tx0 + px - hh.x);
+                const float v = p.k * raw_exp2(-(dx * dx + dy2) * hh.c2);
+                __hip_atomic_fetch_max(row + px, v, __ATOMIC_RELAXED,
+                                       WG_SCOPE ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+    } else {   // four hits at a time, 16 lanes per hit over its box in row-major order
         const int grp = lane >> 4, l16 = lane & 15;
         for (int h0 = 0; h0 < nh; h0 += 4) {
             const int h = h0 + grp;
             if (h >= nh) continue;
             const Hit hh = hits[h];
             const int xlo = hh.box & 255u, xhi = (hh.box >> 8) & 255u, ylo = (hh.box >> 16) & 255u, yhi = hh.box >> 24;
-            const int w = xhi - xlo, area = w * (yhi - ylo);
+            const int w = xhi - xlo, area = w * (yhi - ylo);  // 0 for an empty box
             const float inv_w = 1.0f / (float)max(w, 1);
             for (int q = l16; q < area; q += 16) {
+                // q / w for q < 2048, w <= 128: (q + 0.5) / w is at least 1/256 away from an integer, far more
+                // than the error of the reciprocal
                 const int py = (int)(((float)q + 0.5f) * inv_w);
                 const int px = q - py * w;
                 const float dx = (float)(t.tx0 + xlo + px - hh.x), dy = (float)(t.ty0 + ylo + py - hh.y);
@@ -505,6 +532,14 @@ __device__ __forceinline__ int splat_round(const SplatParams& p, const TileCtx& 
     // the next round overwrites the hit list: order it behind this round's reads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool WG_SCOPE>
+__device__ __forceinline__ int splat_round(const SplatParams& p, const TileCtx& t, int lane, unsigned long long m, const Cand& cand,
+                                           Hit* __restrict__ hits, SmallTile tile, int rows_hint = 0)
+{
+    const int nh = __popcll(m);
+    if ((m >> lane) & 1ull) hits[__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, cand.x, cand.y, cand.r);
+    walk_hits<WG_SCOPE>(p, t, lane, nh, hits, tile, rows_hint);
     return nh;
 }
 
@@ -587,10 +622,10 @@ __device__ __forceinline__ void write_back_rows(const SplatParams& p, const Tile
     }
 }
 
-template <bool CLEAR, int SM, int SRC, int NW = 1>
+template <bool CLEAR, int SM, int SRC, int NW = 1, int TH = kSmallTH>
 __device__ __forceinline__ void small_body(const SplatParams& p, long long linear_group, Hit (*s_hit)[kCand], SmallTile s_tile)
 {
-    constexpr int TW = kSmallTW, TH = kSmallTH;
+    constexpr int TW = kSmallTW;
     constexpr int RPW = TH / NW / 2;  // rows per half-wave in the init / read-back passes
     static_assert(TH % (2 * NW) == 0, "rows must split evenly over the half-waves of the workgroup");
 
@@ -637,6 +672,7 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         // bounding box (group_boxes_kernel); a lane tests one GROUP, and only groups that can reach the tile are
         // walked candidate by candidate — a tile crossed by a lane visits 1-3 rounds instead of all of them
         const int rc = min(max(t.radius, 0), 1 << 30);
+        const int rows_hint = 2 * min(rc, 64) + 1;   // every sample has the same radius: no clipped box is taller
         const ReachBounds rb = reach_bounds(t, rc, t.tx0, t.tx1, t.ty0, t.ty1);
         for (int g0 = 0; g0 < p.n_groups; g0 += kCand) {
             unsigned long long mg = __ballot(group_reaches(load_group_box(p, t, g0 + lane), rb));
@@ -665,9 +701,35 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
                 // groups and comes through here even when none of them is its own) BEHIND the candidate requests, so that
                 // the barrier overlaps their flight
                 if constexpr (NW > 1) prepare_tile();
+                // Round 3: the hits of the (up to four) fetched groups go into ONE list and are walked together when they fit
+                // it — a tile of a coarse scale is crossed by several lanes, each contributing a handful of samples per
+                // group, and one compaction + one walk replaces four dependent ballot / LDS / fence / walk rounds
+                unsigned long long mm[kFetch];
+                int total = 0;
 #pragma unroll
-                for (int u = 0; u < kFetch; ++u)
-                    if (sub_base[u] >= 0) process_round(sub_base[u], cand[u]);
+                for (int u = 0; u < kFetch; ++u) {
+                    mm[u] = sub_base[u] >= 0 ? cull_test(t, sub_base[u], lane, cand[u]) : 0ull;
+                    total += __popcll(mm[u]);
+                }
+                if (total == 0) continue;
+                if (total <= kCand) {
+                    if constexpr (NW == 1) prepare_tile();
+                    int at = 0;
+#pragma unroll
+                    for (int u = 0; u < kFetch; ++u) {
+                        if ((mm[u] >> lane) & 1ull)
+                            s_hit[wave][at + __popcll(mm[u] & ((1ull << lane) - 1ull))] = make_hit(p, t, cand[u].x, cand[u].y, cand[u].r);
+                        at += __popcll(mm[u]);
+                    }
+                    walk_hits<(NW > 1)>(p, t, lane, total, s_hit[wave], s_tile, rows_hint);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kFetch; ++u)
+                        if (mm[u]) {
+                            if constexpr (NW == 1) prepare_tile();
+                            splat_round<(NW > 1)>(p, t, lane, mm[u], cand[u], s_hit[wave], s_tile, rows_hint);
+                        }
+                }
             } while (mg);
         }
     } else {
@@ -728,14 +790,14 @@ __global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
 // test, the candidate requests ahead of the tile set-up barrier (all +-2 %).  What bounds the launch is the chain of
 // dependent round trips of each touched tile (kernel arguments -> count / group boxes -> candidates -> LDS -> barrier ->
 // store, ~8 us) times the tiles that fit a CU at once, not an instruction count.
-template <bool CLEAR, int SM, int NW>
+template <bool CLEAR, int SM, int NW, int TH = kSmallTH>
 __global__ __launch_bounds__(NW * 64) void splat_points_multi_kernel(const MultiParams mp)
 {
     __shared__ Hit s_hit[NW][kCand];
-    __shared__ __attribute__((aligned(16))) float s_tile[kSmallTH][kSmallLdsW];
+    __shared__ __attribute__((aligned(16))) float s_tile[TH][kSmallLdsW];
     int s = 0;
     while (s + 1 < mp.n_scales && (long long)blockIdx.x >= mp.tile_begin[s + 1]) ++s;
-    small_body<CLEAR, SM, 2, NW>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s], s_hit, s_tile);
+    small_body<CLEAR, SM, 2, NW, TH>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s], s_hit, s_tile);
 }
 
 // bounding box (xmin, ymin, xmax, ymax) of every 64 consecutive points of points[b, :, :] (NaN points ignored; a group
@@ -1380,10 +1442,35 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
     // a tile of a coarse scale is crossed by several lanes and has many sample groups to walk: share it among four waves
     // when some scale averages >= 24 samples per tile (config 3: 7.5 / 30 / 113 at strides 4 / 8 / 16); fine scales alone
     // keep one wave per tile (mostly empty tiles would only pay the barriers: 21.7 -> 23.8 us at stride 4)
-    bool heavy = false;
+    // Round 3: ... and only when those coarse tiles are at least half of the launch.  Next to a fine scale with several times
+    // their tile count the coarse tiles' long chains run underneath the fine scale's stream either way, and one wave per tile
+    // (9 KB of LDS, 17-20 tiles resident per CU instead of 8) is what the fine scale wants: config 3 (strides 4 / 8 / 16)
+    // 32.9 -> 28.7 us, its empty-tile floor 21 -> 15 us (profiles/r03_lane_splat_modes_sweep4_tile_height.log)
+    long long coarse_tiles = 0;
     for (int i = 0; i < used; ++i)
-        heavy = heavy || (double)batch * num_points >= 24.0 * (double)mp.scale[i].n_tiles;
+        if ((double)batch * num_points >= 24.0 * (double)mp.scale[i].n_tiles) coarse_tiles += mp.scale[i].n_tiles;
+    bool heavy = 2 * coarse_tiles >= tiles;
     if (const int nw = accv::tune_get("pts_nw", -1); nw > 0) heavy = nw == 4;   // A/B build only
+#ifdef ACCV_TUNE_BUILD
+    if (accv::tune_get("pts_th", 16) == 8) {   // experiment: 128 x 8 tiles, one wave each (5 KB of LDS: 32 tiles per CU)
+        long long t8 = 0;
+        for (int i = 0; i < used; ++i) {
+            SplatParams& p = mp.scale[i];
+            p.tiles_y = (p.H + 7) / 8;
+            p.n_tiles = (long long)batch * p.tiles_x * p.tiles_y;
+            mp.tile_begin[i] = t8;
+            t8 += p.n_tiles;
+        }
+        mp.tile_begin[used] = t8;
+        const dim3 grid8((unsigned)t8);
+        if (clear)
+            hipLaunchKernelGGL((splat_points_multi_kernel<true, 0, 1, 8>), grid8, dim3(64), 0, stream, mp);
+        else
+            hipLaunchKernelGGL((splat_points_multi_kernel<false, 0, 1, 8>), grid8, dim3(64), 0, stream, mp);
+        note_dispatch("splat_points_multi_kernel(TH=8)", 4, 4, clear, 0, grid8, dim3(64));
+        return accv::check_launch("draw_heatmap multi-scale point splat kernel");
+    }
+#endif
     const dim3 grid((unsigned)tiles), block(heavy ? 256 : 64);
 #define ACCV_LAUNCH_POINTS(CL, SMV)                                                                       \
     do {                                                                                                  \

@@ -81,10 +81,21 @@ def main():
     if "--sweep" in sys.argv:
         # A/B build only (make -C accv-lab_amd/csrc tune; ACCV_HIP_LIB=.../libaccv_hip_tune.so): per-scale mode of the point splat
         none_ = torch.zeros(B, dtype=torch.int32, device=dev)
-        for name, knobs in (("default", {"pts_nw": -1}), ("one wave per tile", {"pts_nw": 1}), ("four waves per tile", {"pts_nw": 4})):
+        for name, knobs in (("default", {"pts_nw": -1, "pts_th": 16}), ("one wave per tile", {"pts_nw": 1, "pts_th": 16}),
+                            ("four waves per tile", {"pts_nw": 4, "pts_th": 16}), ("128 x 8 tiles, one wave each", {"pts_nw": -1, "pts_th": 8})):
             for k, v in knobs.items():
                 nat.tune_set(k, v)
             row = {"mode": name}
+            # same maps in every mode
+            chk = [torch.full((B, int(SH / s_), int(SW / s_)), 0.25, device=dev) for s_ in (4.0, 8.0, 16.0)]
+            kk = len(chk)
+            nat.check(lib.accv_draw_points_multiscale_f32((ctypes.c_void_p * kk)(*[m.data_ptr() for m in chk]),
+                                                          (ctypes.c_int * kk)(*[m.size(1) for m in chk]), (ctypes.c_int * kk)(*[m.size(2) for m in chk]),
+                                                          (ctypes.c_float * kk)(4.0, 8.0, 16.0), kk, B, samples.data_ptr(), full.data_ptr(), n, 2, 6.0,
+                                                          1.0, nat.HM_GROUP_BOXES_GIVEN, work.data_ptr(), ws_bytes, stream), "points")
+            torch.cuda.synchronize()
+            sig = [float(m.double().sum()) for m in chk] + [int((m != 0.25).sum()) for m in chk]
+            row["checksum"] = sig
             for sc, strides in (("all", (4.0, 8.0, 16.0)), ("s4", (4.0,)), ("s8", (8.0,)), ("s16", (16.0,))):
                 row[sc] = {"empty": run(strides, none_, 2)["shipped"]["us"], "8 lanes r=2": run(strides, full, 2)["shipped"]["us"],
                            "in-place": run(strides, full, 2, clear=False)["shipped"]["us"]}
