@@ -471,12 +471,9 @@ constexpr int kSmallTW = 128, kSmallTH = 16;
 constexpr int kSmallLdsW = kSmallTW + 4;
 using SmallTile = float (*)[kSmallLdsW];
 
-// compaction of one cull round into the wave's hit list, then the hits' boxes are walked: four hits at a time, 16 lanes
-// per hit.  Pixel updates are LDS float-max atomics (ds_max_f32, no return value): they commute, so neither overlapping
-// boxes of concurrent hits nor successive hits need any ordering — the wave just streams them.  Returns the hit count.
-// (Round 3 measured a row-per-lane walk with padded LDS rows — 12 hits per pass instead of 4: -2 % on config 3, +6 % on
-// its stride-4 map alone, i.e. nothing: the launch is bound by the latency chains of its tiles, not by this loop;
-// profiles/r03_lane_splat_variants_walk_cull_vs_prev.log.)
+// the hits of a cull round (or of several, merged) are walked box by box.  Pixel updates are LDS float-max atomics
+// (ds_max_f32, no return value): they commute, so neither overlapping boxes of concurrent hits nor successive hits need
+// any ordering — the wave just streams them.
 // rows_hint > 0: no clipped box of the list is taller than that (point splats: 2 r + 1) — then a lane takes ONE ROW of one hit
 // and runs along its columns (radius 2: 12 hits per pass, 5 updates per lane) instead of 16 lanes sharing a hit's box in
 // row-major order (4 hits per pass, 2 trips of ~15 dependent instructions for 25 pixels).  With one wave per tile the walk
@@ -780,16 +777,18 @@ __global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
     small_body<CLEAR, SM, 0>(p, blockIdx.x, s_hit, s_tile);
 }
 
-// lane rasters of all scales in one launch: float sample points, two-level cull (SRC = 2), scale from the tile prefix
-// NW = 4 when some scale is coarse enough for a tile to see many samples (decided on the host), else one wave per tile.
-// Round 3 measured the alternatives on config 3 (profiles/r03_lane_splat_*.log): one wave walking a strip of 2 / 4 tiles
-// (empty-tile floor 19.5 -> 16.6 us, but touched tiles then run one after the other on a single wave: 33.5 -> 51 us); a
-// per-scale choice inside one 256-thread launch (fine: a wave per tile, coarse: four waves per tile; 37 KB of LDS and ~100
-// VGPRs for every workgroup halve the resident tiles: 36-37 us); coarse tiles dealt out every 2nd / 4th workgroup instead
-// of first (36 / 43 us: they become the tail); zeros stored ahead of the cull, a row-per-lane walk, a division-free group
-// test, the candidate requests ahead of the tile set-up barrier (all +-2 %).  What bounds the launch is the chain of
-// dependent round trips of each touched tile (kernel arguments -> count / group boxes -> candidates -> LDS -> barrier ->
-// store, ~8 us) times the tiles that fit a CU at once, not an instruction count.
+// lane rasters of all scales in one launch: float sample points, two-level cull (SRC = 2), scale from the tile prefix.
+// NW = 4 (four waves share a tile) when coarse scales — many sample groups per tile — make up at least half of the tiles,
+// else one wave per tile (decided on the host).  What bounds the launch is the chain of dependent round trips of each
+// touched tile (kernel arguments -> count / group boxes -> candidates -> LDS -> store) times the tiles a CU holds at once,
+// not an instruction count (PMC: a wave waits 70-77 % of its life).  Round 3 on config 3, in the order it was found
+// (profiles/r03_lane_splat_*.log, every variant bit-identical): the tile set-up on first use, zeros ahead of the cull, a
+// division-free group test, candidate requests ahead of the set-up barrier, count and box loads in parallel: +-2 % with four
+// waves per tile (33.5 us); strips of 2 / 4 tiles per wave 43-77 us; a per-scale choice inside one 256-thread launch 36-37 us;
+// coarse tiles dealt out every 2nd / 4th workgroup 36 / 43 us; 128 x 8 tiles 28-30 us.  What paid: ONE wave per tile for the
+// whole launch (9 KB of LDS: 17 tiles per CU instead of 8; the coarse tiles' long chains run underneath the fine scale's
+// stream) 28.5 us, the hits of up to four sample groups compacted and walked together 27.7 us, and a row of a splat per
+// lane in that walk (12 hits per pass instead of 4 — with one wave per tile the walk IS part of the chain) 24.0 us.
 template <bool CLEAR, int SM, int NW, int TH = kSmallTH>
 __global__ __launch_bounds__(NW * 64) void splat_points_multi_kernel(const MultiParams mp)
 {
