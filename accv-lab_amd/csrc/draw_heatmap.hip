@@ -484,9 +484,9 @@ __device__ __forceinline__ void walk_hits(const SplatParams& p, const TileCtx& t
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the hit list is complete
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (rows_hint > 0 && rows_hint <= 16) {
+    if (rows_hint > 0 && rows_hint <= 7) {   // (taller boxes: the 16-lane walk below needs fewer trips per hit — measured at r = 5)
         const int per_pass = 64 / rows_hint;
-        const int hl = (int)((float)lane * (1.0f / (float)rows_hint) + 1e-3f);   // lane / rows_hint for lane < 64, rows <= 16
+        const int hl = (int)((float)lane * (1.0f / (float)rows_hint) + 1e-3f);   // lane / rows_hint for lane < 64, rows <= 7
         const int rl = lane - hl * rows_hint;
         for (int h0 = 0; h0 < nh; h0 += per_pass) {
             const int h = h0 + hl;
@@ -535,7 +535,17 @@ __device__ __forceinline__ int splat_round(const SplatParams& p, const TileCtx& 
                                            Hit* __restrict__ hits, SmallTile tile, int rows_hint = 0)
 {
     const int nh = __popcll(m);
-    if ((m >> lane) & 1ull) hits[__popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, cand.x, cand.y, cand.r);
+    int rows = 0;
+    if ((m >> lane) & 1ull) {
+        const Hit mine = make_hit(p, t, cand.x, cand.y, cand.r);
+        hits[__popcll(m & ((1ull << lane) - 1ull))] = mine;
+        rows = (int)(mine.box >> 24) - (int)((mine.box >> 16) & 255u);
+    }
+    if (rows_hint == 0) {   // objects of any radius (splat_small_kernel): the tallest clipped box of this round, wave-uniform
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) rows = max(rows, __shfl_xor(rows, d));
+        rows_hint = max(1, __builtin_amdgcn_readfirstlane(rows));
+    }
     walk_hits<WG_SCOPE>(p, t, lane, nh, hits, tile, rows_hint);
     return nh;
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-scale GPU time of the lane raster: one-level cull (draw_polylines_batched -> splat_small_kernel) vs two-level cull
-(draw_polylines_multiscale with ONE scale -> group boxes + splat_points_multi_kernel), C3's lanes, batch 32."""
+"""Per-scale GPU time of the lane raster: the three-launch formulation (sampler -> integer targets -> draw_heatmap_batched with
+the small-splat kernel: one-level cull) vs the two-launch path draw_polylines_batched takes for small radii since round 3
+(sampler + group boxes -> point splat with its two-level cull), C3's lanes, batch 32."""
 import json
 import os
 import sys
@@ -10,7 +11,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "accv-lab_amd")]
 
 import torch  # noqa: E402
 
-from accvlab.draw_heatmap import draw_polylines_batched, draw_polylines_multiscale  # noqa: E402
+from accvlab.draw_heatmap import draw_polylines_batched  # noqa: E402
+from accvlab.draw_heatmap.lanes import _draw_polylines_via_targets  # noqa: E402
 
 
 def gpu_us(fn, n=200):
@@ -38,9 +40,9 @@ def main():
     for s in (4, 8, 16):
         hm = torch.empty(B, SH // s, SW // s, device=dev)
         for q in (64, 256):
-            one = gpu_us(lambda: draw_polylines_batched(hm, lanes, q, 2, float(s), clear=True))
-            two = gpu_us(lambda: draw_polylines_multiscale([hm], lanes, q, 2, (float(s),), clear=True))
-            print(json.dumps({"stride": s, "samples_per_lane": q, "one_level_us": round(one, 1), "two_level_us": round(two, 1)}))
+            one = gpu_us(lambda: _draw_polylines_via_targets(hm, lanes, q, 2, float(s), clear=True))
+            two = gpu_us(lambda: draw_polylines_batched(hm, lanes, q, 2, float(s), clear=True))
+            print(json.dumps({"stride": s, "samples_per_lane": q, "via_integer_targets_us": round(one, 1), "draw_polylines_batched_us": round(two, 1)}))
 
 
 if __name__ == "__main__":

@@ -108,6 +108,7 @@ def test_lane_raster_validation_and_empty():
 @pytest.mark.parametrize("radius,q", [(2, 64), (1, 200), (5, 17)])
 def test_multiscale_lane_raster_equals_per_scale_calls(ragged, clear, radius, q):
     from accvlab.draw_heatmap import draw_polylines_batched, draw_polylines_multiscale
+    from accvlab.draw_heatmap.lanes import _draw_polylines_via_targets as via_targets
 
     dev = torch.device("cuda", 0)
     b, l, p, sw, sh = 3, 5, 12, 1536.0, 864.0
@@ -122,13 +123,14 @@ def test_multiscale_lane_raster_equals_per_scale_calls(ragged, clear, radius, q)
     draw_polylines_multiscale(fused, pts_d, q, radius, strides, 6.0, 0.9, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
     for i, s in enumerate(strides):
         ref = base[i].clone()
-        draw_polylines_batched(ref, pts_d, q, radius, s, 6.0, 0.9, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
+        via_targets(ref, pts_d, q, radius, s, 6.0, 0.9, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
         assert torch.equal(fused[i], ref), f"stride {s}: fused lane raster differs from the per-scale operator"
     assert any(bool((f != b_).any()) for f, b_ in zip(fused, base))            # something was drawn
 
 
 def test_multiscale_lane_raster_fallback_and_large_radius():
     from accvlab.draw_heatmap import draw_polylines_batched, draw_polylines_multiscale
+    from accvlab.draw_heatmap.lanes import _draw_polylines_via_targets as via_targets
 
     dev = torch.device("cuda", 0)
     pts, _, _ = _lanes(2, 3, 9, 400.0, 300.0, seed=5, ragged=False)
@@ -138,14 +140,14 @@ def test_multiscale_lane_raster_fallback_and_large_radius():
     draw_polylines_multiscale(maps, pts_d, 40, 2, (4.0, 8.0), clear=True)
     for hm, s in zip(maps, (4.0, 8.0)):
         ref = torch.empty_like(hm)
-        draw_polylines_batched(ref, pts_d, 40, 2, s, clear=True)
+        via_targets(ref, pts_d, 40, 2, s, clear=True)
         assert torch.equal(hm, ref)
     # a radius above the small-splat hint: the fused op keeps the box-walking arithmetic, the per-scale op switches to
     # the tile kernel (separable product) -> equal to rounding
     a = [torch.zeros(2, 76, 100, device=dev)]
     draw_polylines_multiscale(a, pts_d, 40, 12, (4.0,), clear=True)
     ref = torch.zeros(2, 76, 100, device=dev)
-    draw_polylines_batched(ref, pts_d, 40, 12, 4.0, clear=True)
+    via_targets(ref, pts_d, 40, 12, 4.0, clear=True)
     assert float((a[0] - ref).abs().max()) <= 1e-6
 
 
@@ -183,6 +185,7 @@ def test_lane_splat_one_and_four_waves_per_tile_agree():
     waves sharing a tile when some scale is coarse; both must equal the per-scale operator bit for bit"""
     from accvlab import _amd_native as nat
     from accvlab.draw_heatmap import draw_polylines_batched, draw_polylines_multiscale
+    from accvlab.draw_heatmap.lanes import _draw_polylines_via_targets as via_targets
 
     dev = torch.device("cuda", 0)
     pts, npts, nlanes = _lanes(4, 6, 14, 2048.0, 1024.0, seed=21, ragged=True)
@@ -197,6 +200,28 @@ def test_lane_splat_one_and_four_waves_per_tile_agree():
             seen.add("block(256)" in nat.last_dispatch())
             for i, s in enumerate(strides):
                 ref = base[i].clone()
-                draw_polylines_batched(ref, pts_d, 128, 2, s, 6.0, 0.8, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
+                via_targets(ref, pts_d, 128, 2, s, 6.0, 0.8, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
                 assert torch.equal(fused[i], ref), (strides, s, clear)
     assert seen == {True, False}, "both launch shapes must have been exercised"
+
+
+def test_single_scale_call_takes_the_point_splat_and_equals_the_three_launch_formulation():
+    """draw_polylines_batched with a radius of a few pixels on an aligned map = the sampler + the point splat of
+    draw_polylines_multiscale with one scale (two launches, two-level cull); other radii / alignments = sampler -> integer
+    targets -> draw_heatmap_batched.  Bit-identical either way."""
+    from accvlab import _amd_native as nat
+    from accvlab.draw_heatmap import draw_polylines_batched
+    from accvlab.draw_heatmap.lanes import _draw_polylines_via_targets as via_targets
+
+    dev = torch.device("cuda", 0)
+    pts, npts, nlanes = _lanes(3, 5, 11, 1024.0, 512.0, seed=33, ragged=True)
+    pts_d, npts_d, nlanes_d = torch.from_numpy(pts).to(dev), torch.from_numpy(npts).to(dev), torch.from_numpy(nlanes).to(dev)
+    for stride, radius, width, kernel in ((2.0, 2, 512, "splat_points_multi_kernel"), (4.0, 0, 256, "splat_points_multi_kernel"),
+                                          (4.0, 12, 256, "splat_kernel"), (4.0, 2, 254, "splat_kernel")):
+        for clear in (True, False):
+            base = torch.rand(3, int(512 / stride), width, generator=torch.Generator().manual_seed(2)).mul_(0.3).to(dev)
+            got, ref = base.clone(), base.clone()
+            draw_polylines_batched(got, pts_d, 96, radius, stride, 6.0, 0.7, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
+            assert kernel in nat.last_dispatch(), (stride, radius, width, nat.last_dispatch())
+            via_targets(ref, pts_d, 96, radius, stride, 6.0, 0.7, num_points=npts_d, num_lanes=nlanes_d, clear=clear)
+            assert torch.equal(got, ref), (stride, radius, width, clear)
