@@ -226,11 +226,18 @@ public:
     // uses it — the pool's and the one its python object holds — and the TensorImpl in turn keeps that python object alive
     // with ONE python reference while other C++ references exist (c10/util/intrusive_ptr.h, "PyObject preservation"); any
     // python variable, container, view (`_base`) or C++ holder adds to one of the two counts.
+    // ... and the object must be as this module made it: no autograd metadata (somebody called requires_grad_() on it), no
+    // names, no python attributes set on it — none of which re-pointing would reset.
     static bool nobody_else_holds(const at::Tensor& t)
     {
-        const c10::impl::PyObjectSlot* slot = t.unsafeGetTensorImpl()->pyobj_slot();
-        if (slot->load_pyobj() == nullptr) return t.use_count() == 1;
-        return t.use_count() == 2 && slot->has_unique_reference();
+        at::TensorImpl* impl = t.unsafeGetTensorImpl();
+        if (impl->autograd_meta() != nullptr || impl->has_named_tensor_meta()) return false;
+        const c10::impl::PyObjectSlot* slot = impl->pyobj_slot();
+        PyObject* obj = slot->load_pyobj();
+        if (obj == nullptr) return t.use_count() == 1;
+        if (!(t.use_count() == 2 && slot->has_unique_reference())) return false;
+        PyObject** dict = _PyObject_GetDictPtr(obj);
+        return dict == nullptr || *dict == nullptr || PyDict_Size(*dict) == 0;
     }
     static bool& recycling_enabled()
     {

@@ -244,6 +244,16 @@ def test_output_tensor_objects_are_recycled_only_when_nothing_refers_to_them():
         seen.add((id(r["a"]), id(r["b"][0]), id(r["b"][1])))
         del r
     assert len(seen) <= 2, seen
+    # an output the caller changed as an OBJECT (autograd flag, python attribute) is not handed out again
+    for k in (30, 31):
+        r = result(k)
+        r["a"].requires_grad_(True)
+        r["b"][0].note = "mine"
+        del r
+    for k in (32, 33, 34):
+        r = result(k)
+        assert not r["a"].requires_grad and not hasattr(r["b"][0], "note") and r["a"].tolist() == [float(k)] * 4
+        del r
     # a different structure at the same positions: dtype mismatch -> fresh tensors, correct values
     chunk = torch.arange(80, dtype=torch.uint8)
     other = _views_of(host, [torch.zeros(16, dtype=torch.uint8), torch.zeros(6, dtype=torch.int32)], chunk, np.array([0, 16], dtype=np.int64))
