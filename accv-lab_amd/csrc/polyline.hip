@@ -337,11 +337,16 @@ int accv_polyline_sample_boxes(const void* points, const void* distances, const 
     // keep the launch at <= ~4096 workgroups (batch 64, 5000 x 5000: 50 us with one workgroup per polyline; profiles/r02_bench_published.jsonl)
     // long polylines take 1024-thread workgroups: the scan over the points is the serial part of a workgroup (5000 points:
     // 20 segments per thread with 256 threads, 5 with 1024)
-    const bool wide = max_points >= 2048;
+    const bool wide = max_points >= accv::tune_get("poly_wide", 2048);
     const long long threads = wide ? 1024 : kThreads;
     long long chunks = 1;
     // (every chunk repeats the scan over max_points, so a chunk should hold at least ~max_points / 4 queries)
-    const long long min_chunk = std::max<long long>(threads, ((max_points / 4 + threads - 1) / threads) * threads);
+    long long min_chunk = std::max<long long>(threads, ((max_points / 4 + threads - 1) / threads) * threads);
+    // few polylines: the chip is idle anyway, so every thread takes ONE query and the queries of a polyline spread over as
+    // many workgroups as that needs (each repeats the scan) — a second query per thread is a second serial pass of loads,
+    // binary search and interpolation (batch 1, 2000 x 2000: 9.1 -> 7.7 us, 5000 x 5000: 12.3 -> 10.4 us;
+    // profiles/r03_tails_probe_sampler_launch_shapes.log)
+    if (batch * ((max_distances + threads - 1) / threads) <= accv::tune_get("poly_spread", 512)) min_chunk = threads;
     if (p.out_points && !p.use_scratch && max_distances >= 2 * min_chunk && batch < 2048)
         chunks = std::max<long long>(1, std::min<long long>((max_distances + min_chunk - 1) / min_chunk, 4096 / batch));
     const long long per_chunk = (max_distances + chunks - 1) / chunks;

@@ -57,24 +57,33 @@ def main():
             elif not (torch.equal(ref[0], snap[0]) and torch.equal(ref[1], snap[1])):
                 row[name] = str(row[name]) + "!"
         print(json.dumps({"mask_to_indices": f"{b} x {w}", "us": row}))
-    for batch, npts, nq in ((1, 1000, 1000), (1, 2000, 2000), (1, 5000, 1), (1, 5000, 5000), (64, 2000, 2000), (64, 5000, 1)):
-        pts = torch.rand(batch, npts, 2, generator=g).cumsum(1).to(dev)
-        dist = torch.rand(batch, nq, generator=g).sort(1).values.to(dev)
-        out = torch.empty(batch, nq, 2, device=dev)
-        row, ref = {}, None
-        for name, lib in libs.items():
-            nb = lib.accv_polyline_scratch_bytes(batch, npts, 0)
-            scr = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
-            fn = lambda: nat.check(lib.accv_polyline_sample(pts.data_ptr(), dist.data_ptr(), None, None, out.data_ptr(), None, batch, npts,
-                                                              nq, 2, 0, 0, 1, scr.data_ptr(), nb, stream), "poly")
-            out.fill_(-7.0)
-            row[name] = gpu_us(fn)
-            snap = out.clone()
-            if ref is None:
-                ref = snap
-            elif not torch.equal(ref.view(torch.int32), snap.view(torch.int32)):
-                row[name] = str(row[name]) + "!"
-        print(json.dumps({"polyline sample": f"batch {batch}, {npts} points x {nq} distances", "us": row}))
+    knobs = [{}]
+    if "--sweep" in sys.argv:     # A/B build only (ACCV_HIP_LIB=.../libaccv_hip_tune.so)
+        knobs = [{"poly_wide": 2048, "poly_spread": 0}, {"poly_wide": 2048, "poly_spread": 512}, {"poly_wide": 1024, "poly_spread": 0},
+                 {"poly_wide": 1024, "poly_spread": 512}, {"poly_wide": 4096, "poly_spread": 512}]
+    for kn in knobs:
+      for k_, v_ in kn.items():
+        nat.tune_set(k_, v_)
+      if kn:
+        print(json.dumps({"knobs": kn}))
+      for batch, npts, nq in ((1, 1000, 1000), (1, 2000, 2000), (1, 5000, 1), (1, 5000, 5000), (64, 2000, 2000), (64, 5000, 1)):
+          pts = torch.rand(batch, npts, 2, generator=g).cumsum(1).to(dev)
+          dist = torch.rand(batch, nq, generator=g).sort(1).values.to(dev)
+          out = torch.empty(batch, nq, 2, device=dev)
+          row, ref = {}, None
+          for name, lib in libs.items():
+              nb = lib.accv_polyline_scratch_bytes(batch, npts, 0)
+              scr = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+              fn = lambda: nat.check(lib.accv_polyline_sample(pts.data_ptr(), dist.data_ptr(), None, None, out.data_ptr(), None, batch, npts,
+                                                                nq, 2, 0, 0, 1, scr.data_ptr(), nb, stream), "poly")
+              out.fill_(-7.0)
+              row[name] = gpu_us(fn)
+              snap = out.clone()
+              if ref is None:
+                  ref = snap
+              elif not torch.equal(ref.view(torch.int32), snap.view(torch.int32)):
+                  row[name] = str(row[name]) + "!"
+          print(json.dumps({"polyline sample": f"batch {batch}, {npts} points x {nq} distances", "us": row}))
 
 
 if __name__ == "__main__":
