@@ -9,6 +9,7 @@
 #include <pybind11/numpy.h>
 #include <pybind11/stl.h>
 #include <torch/extension.h>
+#include <torch/version.h>
 
 #include <cstdint>
 #include <vector>
@@ -239,9 +240,16 @@ public:
         PyObject** dict = _PyObject_GetDictPtr(obj);
         return dict == nullptr || *dict == nullptr || PyDict_Size(*dict) == 0;
     }
+    // nobody_else_holds() reads the reference-count convention of torch >= 2.10 (the python object of a tensor owns one C++
+    // reference; c10/util/intrusive_ptr.h, kHasPyObject); with any other torch the pool stays off
+#if TORCH_VERSION_MAJOR > 2 || (TORCH_VERSION_MAJOR == 2 && TORCH_VERSION_MINOR >= 10)
+    static constexpr bool kRecyclingSupported = true;
+#else
+    static constexpr bool kRecyclingSupported = false;
+#endif
     static bool& recycling_enabled()
     {
-        static bool on = true;
+        static bool on = kRecyclingSupported;
         return on;
     }
     void make_packed_views(const py::array_t<int64_t>& idx, const py::array_t<int64_t>& chunk_of,
@@ -405,7 +413,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           },
           "drop the output tensors of the last packed copy that are kept for re-use (and the chunk storage they pin)");
     m.def("set_output_recycling", [](bool on) {
-        Tree::recycling_enabled() = on;
+        Tree::recycling_enabled() = on && Tree::kRecyclingSupported;
         if (!on)
             for (auto& g : Tree::recycled().gen) std::vector<at::Tensor>().swap(g);
     });
