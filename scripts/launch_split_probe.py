@@ -51,6 +51,28 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / iters
 
+    import ctypes
+    alts = {}
+    for path in [a for a in sys.argv[1:] if a.endswith(".so")]:      # further builds of the library: shard sizes, same process
+        h = ctypes.CDLL(os.path.abspath(path))
+        h.accv_draw_heatmap_batched_f32.restype, h.accv_draw_heatmap_batched_f32.argtypes = nat.SIGNATURES["accv_draw_heatmap_batched_f32"]
+        alts[os.path.basename(path).replace("libaccv_hip_", "").replace(".so", "")] = h
+    if alts:
+        libs = {"shipped": lib, **alts}
+        for frames in (8, 16, 32, 64):
+            row = {}
+            for name, handle in libs.items():
+                def one(lo=0, hi=frames, handle=handle):
+                    nat.check(handle.accv_draw_heatmap_batched_f32(hm.data_ptr() + lo * H * W * 4, hi - lo, 0, H, W, c.data_ptr() + lo * nmax * 8,
+                                                                   r.data_ptr() + lo * nmax * 4, n.data_ptr() + lo * 8, None, nmax, 6.0, 1.0,
+                                                                   flags, stream), "draw")
+                # every shard of the split, slowest one reported (as bench.py's strong-scaling prediction does)
+                per = []
+                for k in range(B // frames):
+                    per.append(timed(lambda: one(k * frames, (k + 1) * frames), warm=100, iters=200))
+                row[name] = {"slowest_us": round(max(per) * 1e3, 2), "fastest_us": round(min(per) * 1e3, 2)}
+            print(json.dumps({"frames_per_launch": frames, **row}))
+        return
     variants = {
         "1 x 64 frames": lambda: split(1),
         "2 x 32 frames (same 531 MB map)": lambda: split(2),
