@@ -3,6 +3,13 @@ python twin) against the oracle: pack / mask / split round trips over random sam
 samples and nested batch dimensions; compaction and pad fill of CPU tensors."""
 import numpy as np
 import pytest
+
+
+def _seeds(n):
+    """seed range of a sweep; ACCV_FUZZ_SCALE=k runs k times as many seeds (soak runs: profiles/r03_fuzz_soak.log)"""
+    import os
+    return range(n * max(1, int(os.environ.get("ACCV_FUZZ_SCALE", "1"))))
+
 import torch
 
 from oracle import h2 as oracle_h2
@@ -15,7 +22,7 @@ def _rand(shape, dt, rng):
     return torch.from_numpy(a > 30) if dt == torch.bool else torch.from_numpy(a).to(dt)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", _seeds(10))
 def test_combine_mask_split_round_trip_random(seed):
     from accvlab.batching_helpers import combine_data
 
@@ -40,7 +47,7 @@ def test_combine_mask_split_round_trip_random(seed):
             assert np.array_equal(filled.tensor.numpy(), oracle_h2.pad_fill(want, sizes, 5))
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_nested_batch_dims_round_trip_random(seed):
     from accvlab.batching_helpers import combine_data
 
@@ -52,6 +59,12 @@ def test_nested_batch_dims_round_trip_random(seed):
         nested = [[_rand((int(rng.integers(0, 5)),) + feat, dt, rng) for _ in range(inner_b)] for _ in range(outer)]
         rb = combine_data(nested, flatten_batch_dims=False)
         assert rb.num_batch_dims == 2 and tuple(rb.sample_sizes.shape) == (outer, inner_b)
+        if all(t.shape[0] == 0 for row in nested for t in row):
+            # nothing but empty samples: the reference returns an empty float32 batch without the trailing dimensions
+            # (batched_processing_py.py:524-533) — found by the soak run (ACCV_FUZZ_SCALE), kept as the reference has it
+            assert tuple(rb.tensor.shape) == (outer, inner_b, 0) and rb.tensor.dtype == torch.float32
+            assert int(rb.sample_sizes.sum()) == 0
+            continue
         for i in range(outer):
             for j in range(inner_b):
                 n = nested[i][j].shape[0]
@@ -64,7 +77,7 @@ def test_nested_batch_dims_round_trip_random(seed):
         assert flat.num_batch_dims == 1 and flat.sample_sizes.tolist() == [t.shape[0] for row in nested for t in row]
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_cpu_compaction_random_against_the_oracle(seed):
     from accvlab.batching_helpers import batched_bool_indexing, get_compact_lists, get_indices_from_mask
 
@@ -134,7 +147,7 @@ def _check(rbatch, want_leaves, want_batch_shape, what):
     assert torch.equal(rbatch.mask, cols < rbatch.sample_sizes.unsqueeze(-1)), what + ": mask"
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", _seeds(12))
 def test_ragged_batch_shape_operations_against_the_list_model(seed):
     rng = np.random.default_rng(9800 + seed)
     for case in range(8):
@@ -208,7 +221,7 @@ def _same_tree(a, b):
     return a is b or a == b
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", _seeds(8))
 def test_pack_batch_random_trees_round_trip(seed):
     """DataLoader hook: pack_batch -> (pickle) -> unpack reproduces nesting, dtypes, shapes and bytes for random trees with empty,
     non-contiguous, numpy and non-tensor leaves; every packed leaf starts at a multiple of the requested alignment"""
@@ -227,7 +240,7 @@ def test_pack_batch_random_trees_round_trip(seed):
         assert again.num_tensors == pk.num_tensors and again.num_packed == pk.num_packed
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_lane_sampler_host_path_random_against_the_oracle(seed):
     """interpolate / lengths on CPU tensors (accv_polyline_sample_host, double accumulation as polyline_cpu.cpp:111-132):
     float32 and float64, fixed and ragged, zero-length segments, empty polylines, relative mode"""
@@ -266,7 +279,7 @@ def test_lane_sampler_host_path_random_against_the_oracle(seed):
             assert (np.isnan(wl_) and np.isnan(rl[i])) or abs(rl[i] - wl_) <= tol
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", _seeds(8))
 def test_masked_reductions_against_the_list_model(seed):
     """sum_over_targets / average_over_targets (empty samples: 0 or NaN) / apply_mask_to_tensor / squeeze_except_batch_and_sample
     over random batch shapes and positions of the non-uniform dimension, against per-sample sums of the valid entries"""

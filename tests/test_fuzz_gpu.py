@@ -6,6 +6,13 @@ from types import SimpleNamespace
 
 import numpy as np
 import pytest
+
+
+def _seeds(n):
+    """seed range of a sweep; ACCV_FUZZ_SCALE=k runs k times as many seeds (soak runs: profiles/r03_fuzz_soak.log)"""
+    import os
+    return range(n * max(1, int(os.environ.get("ACCV_FUZZ_SCALE", "1"))))
+
 import torch
 
 from oracle import h1 as oracle
@@ -37,7 +44,7 @@ def _random_h1_case(rng):
     return h, w, b, n_max, counts, centers, radii.astype(np.int32)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", _seeds(12))
 def test_h1_random_geometry_against_the_oracle(seed):
     from accvlab import _amd_native as nat
     from accvlab.draw_heatmap import draw_heatmap_batched, ops
@@ -75,7 +82,7 @@ _DTYPES = [torch.float32, torch.float16, torch.int64, torch.int32, torch.float64
 _MASK_DTYPES = _DTYPES + [torch.uint8, torch.bool]
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", _seeds(8))
 def test_h2_random_gather_scatter_compaction_against_the_oracle(seed):
     from accvlab.batching_helpers import RaggedBatch, batched_bool_indexing, batched_indexing_access, \
         batched_inverse_indexing_access, get_indices_from_mask
@@ -126,7 +133,7 @@ def test_h2_random_gather_scatter_compaction_against_the_oracle(seed):
             assert np.array_equal(ind.tensor[i, : want_cnt[i]].cpu().numpy(), want_idx[i][: want_cnt[i]])
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_h1_flat_api_random_planes_against_the_oracle(seed):
     """draw_heatmap (flat input): random plane indices incl. out-of-range ones (ignored), empty planes, N below and above the
     single-launch binning limit"""
@@ -151,7 +158,7 @@ def test_h1_flat_api_random_planes_against_the_oracle(seed):
         assert err <= 1e-5, f"seed {seed} case {case}: P {p} {h}x{w} N {n}: max abs err {err}"
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_h3_random_trees_round_trip_bit_exact(seed):
     """start_copy over random nestings / dtypes / empty, non-contiguous and numpy leaves, to the GPU and back, both modes, several
     packing parameters, also through the DataLoader hook (pack_batch): structure, dtypes, shapes and bytes are preserved"""
@@ -179,7 +186,7 @@ def _np(t):
     return t.view(torch.int16).numpy() if t.dtype == torch.bfloat16 else t.numpy()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", _seeds(8))
 def test_h2_random_write_mapping_mask_padfill_boolwrite_against_the_oracle(seed):
     """the writing half of batching_helpers: indexing write, index mapping, mask from indices, pad fill, boolean write-back —
     random shapes, dtypes, negative (wrapping) indices, ragged masks"""
@@ -228,7 +235,7 @@ def test_h2_random_write_mapping_mask_padfill_boolwrite_against_the_oracle(seed)
         assert np.array_equal(_np(got.tensor if hasattr(got, "tensor") else got), want), f"bool write {seed}/{case}"
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_lane_sampler_random_polylines_against_the_oracle(seed):
     """interpolate / lengths (fixed and ragged): random point counts incl. 0 and 1, repeated points (zero-length segments),
     queries before the start and beyond the end, relative mode, 2-D and 3-D points.  atol 1e-5 relative to the polyline scale
@@ -268,7 +275,7 @@ def test_lane_sampler_random_polylines_against_the_oracle(seed):
             assert (np.isnan(wl_) and np.isnan(lens[i])) or abs(lens[i] - wl_) <= 4e-5, f"lane length {seed}/{case} sample {i}"
 
 
-@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("seed", _seeds(5))
 def test_wide_mask_compaction_random_against_the_oracle(seed):
     """mask -> indices on the one-wave, the multi-wave and the segmented (two-pass, >= 8192 columns) paths: random widths that
     are no multiples of the segment size, random densities incl. all-False / all-True rows, ragged validity"""
@@ -295,7 +302,7 @@ def test_wide_mask_compaction_random_against_the_oracle(seed):
             assert np.array_equal(g[i, : want_cnt[i]], want_idx[i][: want_cnt[i]]), f"indices {seed}/{case} w {w} row {i}"
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_ragged_batch_shape_operations_on_the_gpu_against_the_list_model(seed):
     """the model-based sweep of tests/test_fuzz_cpu.py on GPU tensors (mask and pad-fill kernels, split without read-back)"""
     import test_fuzz_cpu as m
@@ -334,7 +341,7 @@ def test_ragged_batch_shape_operations_on_the_gpu_against_the_list_model(seed):
         check(rbatch.cpu().to_device(DEV), leaves, shape, "cpu -> device round trip")
 
 
-@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("seed", _seeds(5))
 def test_matched_pair_loss_random_against_the_composition(seed):
     """fused gather + loss + masked sum against the same thing composed from the package's operators (float64 on the host)"""
     from accvlab.batching_helpers import RaggedBatch, matched_pair_loss_sum
@@ -366,7 +373,7 @@ def test_matched_pair_loss_random_against_the_composition(seed):
         assert np.allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5), f"matched loss {seed}/{case} {kind}"
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_multiscale_and_lane_raster_random_against_the_per_scale_operators(seed):
     """one-launch multi-scale box maps and lane rasters == the per-scale operators, bit for bit, over random strides, map shapes
     (incl. ones the fused kernels do not take), counts incl. zero, lanes with few / no points, fused clear and in-place"""
@@ -414,7 +421,7 @@ def test_multiscale_and_lane_raster_random_against_the_per_scale_operators(seed)
             assert torch.equal(fused[i], ref), f"lane raster {seed}/{case} stride {s} shape {shapes[i]} q {q} r {radius}"
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_h2_random_gradients_against_torch_autograd(seed):
     """backward of gather (repeated indices accumulate), inverse, write and mapping against the same expressions written with torch
     advanced indexing on the GPU (float64: the atomics' summation order is then irrelevant at 1e-10)"""
@@ -468,7 +475,7 @@ def test_h2_random_gradients_against_torch_autograd(seed):
         assert torch.allclose(into2.grad, i2_ref.grad, rtol=1e-10, atol=1e-10), f"mapping destination grad {seed}/{case}"
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_h2_multi_batch_dims_and_moved_index_dim_equal_the_flat_case(seed):
     """several batch dimensions and an index dimension that is not the first data dimension: gather, write and boolean
     compaction must equal the same call on the flattened batch with the indexed dimension moved to the front"""
@@ -514,7 +521,7 @@ def test_h2_multi_batch_dims_and_moved_index_dim_equal_the_flat_case(seed):
         assert torch.equal(got.tensor.reshape((total,) + tuple(got.tensor.shape[nb:])), flat.tensor), f"bool indexing {seed}/{case}"
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", _seeds(4))
 def test_h1_extreme_coordinates_and_radii(seed):
     """centres anywhere in int32 and radii up to 2^30 - 1 (beyond that 2r+1 overflows int32 in the reference as well,
     cuh:61-62): the 32-bit cull must stay conservative, the exact box must be computed in 64 bits, nothing may be written outside
@@ -551,7 +558,7 @@ def test_h1_extreme_coordinates_and_radii(seed):
         assert err <= 1e-5, f"extreme {seed}/{case}: max abs err {err}"
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", _seeds(4))
 def test_target_front_end_random_against_float32_numpy(seed):
     """get_centers_and_radii: c = int(c / stride), r = max(1, ceil(min edge distance / stride)) in IEEE float32
     (packages/draw_heatmap/tests/_test_helpers.py:20-28) — bit-exact against numpy float32 for random boxes incl. degenerate and
@@ -767,7 +774,7 @@ def test_whole_target_prep_step_replays_from_one_hip_graph():
             assert torch.equal(a, w), f"replay with inputs {seed}: output {k} differs from the eager result"
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_combine_data_to_the_gpu_random(seed):
     """combine_data with a GPU target: CPU samples (pinned padded pack or flat + pack kernel, depending on the size), GPU samples,
     nested lists with and without flattening, shared sample sizes, gradients — equal to the CPU result of the same call"""
