@@ -118,6 +118,11 @@ public:
         TORCH_CHECK(of.shape(0) == ix.shape(0) && dt.shape(0) == ix.shape(0) && nd.shape(0) == ix.shape(0),
                     "packed metadata arrays differ in length");
         const int64_t storage_bytes = (int64_t)storage_holder.storage().nbytes();
+        // the views of a PackedBatch that went to the GPU are outputs like those of make_packed_views: recycled (see there);
+        // the CPU unpack (as_leaves) hands its views to the caller as the batch's leaves and keeps out of the pool
+        const bool pool_this = !as_leaves && recycling_enabled() && storage_bytes <= kRecycleMaxBytes;
+        std::vector<at::Tensor> next;
+        if (pool_this) next.reserve((size_t)ix.shape(0));
         py::ssize_t cursor = 0;
         std::vector<int64_t> sizes;
         for (py::ssize_t k = 0; k < ix.shape(0); ++k) {
@@ -135,15 +140,26 @@ public:
             const int64_t byte_off = storage_holder.storage_offset() * (int64_t)storage_holder.element_size() + base + of(k);
             TORCH_CHECK(byte_off % es == 0, "packed offset ", byte_off, " is not a multiple of the element size ", es);
             TORCH_CHECK(byte_off >= 0 && byte_off + numel * es <= storage_bytes, "packed leaf lies outside the buffer");
-            auto impl = c10::make_intrusive<at::TensorImpl>(c10::Storage(storage_holder.storage()),
-                                                            storage_holder.key_set(), meta);
-            impl->set_sizes_contiguous(sizes);
-            impl->set_storage_offset(byte_off / es);
-            at::Tensor view(std::move(impl));
+            at::Tensor view;
+            if (pool_this) view = take_recycled((size_t)k, meta, storage_holder);
+            if (view.defined()) {
+                at::TensorImpl* impl = view.unsafeGetTensorImpl();
+                impl->set_storage_keep_dtype(c10::Storage(storage_holder.storage()));
+                impl->set_sizes_contiguous(sizes);
+                impl->set_storage_offset(byte_off / es);
+            } else {
+                auto impl = c10::make_intrusive<at::TensorImpl>(c10::Storage(storage_holder.storage()),
+                                                                storage_holder.key_set(), meta);
+                impl->set_sizes_contiguous(sizes);
+                impl->set_storage_offset(byte_off / es);
+                view = at::Tensor(std::move(impl));
+            }
             const size_t li = (size_t)ix(k);
+            if (pool_this) next.push_back(view);
             outs_.at(li) = view;
             if (as_leaves) leaves_.at(li) = view;
         }
+        if (pool_this) keep_for_recycling(std::move(next));
     }
 
     int64_t num_leaves() const { return (int64_t)leaves_.size(); }
@@ -252,6 +268,30 @@ public:
         static bool on = kRecyclingSupported;
         return on;
     }
+    // k-th packed output of a call: a kept tensor of an earlier call that is free to be re-pointed (older generation first),
+    // or an undefined tensor
+    static at::Tensor take_recycled(size_t k, const caffe2::TypeMeta& dtype, const at::Tensor& chunk)
+    {
+        if (!recycling_enabled()) return at::Tensor();
+        Pool& pool = recycled();
+        for (int g = 1; g >= 0; --g) {
+            if (k >= pool.gen[g].size()) continue;
+            at::Tensor& old = pool.gen[g][k];
+            if (old.defined() && nobody_else_holds(old) && old.dtype() == dtype && old.key_set() == chunk.key_set() &&
+                old.device() == chunk.device())
+                return std::move(old);
+        }
+        return at::Tensor();
+    }
+    // the views of THIS call become the younger generation; what is left of the older one is released
+    static void keep_for_recycling(std::vector<at::Tensor>&& views)
+    {
+        Pool& pool = recycled();
+        pool.gen[1].swap(pool.gen[0]);
+        pool.gen[0].swap(views);
+        std::vector<at::Tensor>().swap(views);
+    }
+
     void make_packed_views(const py::array_t<int64_t>& idx, const py::array_t<int64_t>& chunk_of,
                            const py::array_t<int64_t>& offsets, const std::vector<at::Tensor>& chunks,
                            const py::array_t<int64_t>& bases)
@@ -263,7 +303,6 @@ public:
         int64_t chunk_bytes = 0;
         for (const auto& c : chunks) chunk_bytes += (int64_t)c.storage().nbytes();
         const bool pool_this = recycling_enabled() && chunk_bytes <= kRecycleMaxBytes;
-        Pool& pool = recycled();
         std::vector<at::Tensor> next;
         if (pool_this) next.reserve((size_t)ix.shape(0));
         for (py::ssize_t k = 0; k < ix.shape(0); ++k) {
@@ -272,18 +311,12 @@ public:
             const int64_t es = (int64_t)t.element_size();
             const int64_t byte_off = chunk.storage_offset() + bs(ck(k)) + of(k);
             TORCH_CHECK(byte_off % es == 0, "packed offset ", byte_off, " is not a multiple of the element size ", es);
-            at::Tensor view;
-            for (int g = 1; g >= 0 && recycling_enabled() && !view.defined(); --g) {   // the older generation first
-                if ((size_t)k >= pool.gen[g].size()) continue;
-                at::Tensor& old = pool.gen[g][(size_t)k];
-                if (old.defined() && nobody_else_holds(old) && old.dtype() == t.dtype() && old.key_set() == chunk.key_set() &&
-                    old.device() == chunk.device()) {
-                    view = std::move(old);   // nobody else holds it: re-point it
-                    at::TensorImpl* impl = view.unsafeGetTensorImpl();
-                    impl->set_storage_keep_dtype(c10::Storage(chunk.storage()));
-                    if (!(impl->sizes() == t.sizes() && impl->strides() == t.strides())) impl->set_sizes_and_strides(t.sizes(), t.strides());
-                    impl->set_storage_offset(byte_off / es);
-                }
+            at::Tensor view = take_recycled((size_t)k, t.dtype(), chunk);
+            if (view.defined()) {   // nobody else holds it: re-point it
+                at::TensorImpl* impl = view.unsafeGetTensorImpl();
+                impl->set_storage_keep_dtype(c10::Storage(chunk.storage()));
+                if (!(impl->sizes() == t.sizes() && impl->strides() == t.strides())) impl->set_sizes_and_strides(t.sizes(), t.strides());
+                impl->set_storage_offset(byte_off / es);
             }
             if (!view.defined()) {
                 // build the view directly on the chunk's storage (no intermediate empty tensor + set_)
@@ -295,10 +328,7 @@ public:
             if (pool_this) next.push_back(view);
             outs_[(size_t)ix(k)] = std::move(view);
         }
-        // generations move on: what is left of the older one is released, the last call's become the older one
-        pool.gen[1].swap(pool.gen[0]);
-        pool.gen[0].swap(next);
-        std::vector<at::Tensor>().swap(next);
+        keep_for_recycling(std::move(next));
     }
 
     py::object rebuild() const

@@ -4,5 +4,6 @@ ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/r03"
 mkdir -p "$OUT"
 cd "$ROOT"
-ACCV_FUZZ_SCALE=60 timeout -k 10 1000 python -m pytest tests/test_fuzz_gpu.py tests/test_fuzz_cpu.py -m "gpu or not gpu" -q -p no:cacheprovider > "$OUT/fuzz_soak.log" 2>&1; rc=$?; echo "[r03] soak rc=$rc $(tail -1 $OUT/fuzz_soak.log)"
-[ $rc -eq 0 ] || tail -80 "$OUT/fuzz_soak.log" | cut -c1-250
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > "$OUT/gpu_tests_18.log" 2>&1; rc=$?; echo "[r03] pytest rc=$rc $(tail -1 $OUT/gpu_tests_18.log)"
+[ $rc -eq 0 ] || { tail -60 "$OUT/gpu_tests_18.log"; exit 1; }
+timeout -k 10 400 python scripts/bench_secondary.py --configs F4 > "$OUT/secondary_f4.log" 2>&1; echo "[r03] f4 rc=$?"; cat "$OUT/secondary_f4.log"
