@@ -66,7 +66,7 @@ def main():
         nat.tune_set(k_, v_)
       if kn:
         print(json.dumps({"knobs": kn}))
-      for batch, npts, nq in ((1, 1000, 1000), (1, 2000, 2000), (1, 5000, 1), (1, 5000, 5000), (64, 2000, 2000), (64, 5000, 1)):
+      for batch, npts, nq in ((256, 24, 256), (64, 100, 100), (1, 100, 100), (64, 500, 500), (1, 1000, 1000), (1, 2000, 2000), (1, 5000, 1), (1, 5000, 5000), (64, 2000, 2000), (64, 5000, 1)):
           pts = torch.rand(batch, npts, 2, generator=g).cumsum(1).to(dev)
           dist = torch.rand(batch, nq, generator=g).sort(1).values.to(dev)
           out = torch.empty(batch, nq, 2, device=dev)
