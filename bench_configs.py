@@ -32,6 +32,13 @@ PCIE_GBPS = 63.0     # PCIe Gen5 x16 (MI355X_MICROARCH.md, chip-level parameters
 HBM_GBPS = 8000.0
 
 
+def _best_of(fn, warm, iters, sync=None, blocks=2):
+    """the faster of `blocks` timed blocks (each behind its own warm-up): inside bench.py these configs run right behind
+    thousands of launches of the headline kernel and the CPU baseline, and the first block after such a change of load reads
+    up to 15 % slow (clocks, allocator state) — profiles/r03_bench.json vs r03_bench_first_k20.json"""
+    return min(_timeit(fn, warm, iters, sync) for _ in range(blocks))
+
+
 def _timeit(fn, warm, iters, sync=None):
     for _ in range(warm):
         fn()
@@ -100,8 +107,8 @@ def config2(n=10_000):
     leaves = _leaves(tree)
     nbytes = sum(t.numel() * t.element_size() for t in leaves)
     sync = torch.cuda.synchronize
-    t_bg = _timeit(lambda: start_copy(tree, dev).get(), 10, 50, sync)
-    t_in = _timeit(lambda: start_copy(tree, dev, use_background_thread=False).get(), 10, 50, sync)
+    t_bg = _best_of(lambda: start_copy(tree, dev).get(), 10, 50, sync, blocks=3)
+    t_in = _best_of(lambda: start_copy(tree, dev, use_background_thread=False).get(), 10, 50, sync, blocks=3)
     small = wl.meta_tensor_tree(528, seed=0)
     t_bg_s = _timeit(lambda: start_copy(small, dev).get(), 20, 200, sync)
     t_in_s = _timeit(lambda: start_copy(small, dev, use_background_thread=False).get(), 20, 200, sync)
@@ -113,7 +120,8 @@ def config2(n=10_000):
                               "pinned pack + async H2D, start_copy(...).get(), default use_background_thread=True"},
           roofline={"bound": "pcie", "achieved": nbytes / t_bg / 1e9, "peak": PCIE_GBPS, "unit": "GB/s",
                     "frac": nbytes / t_bg / 1e9 / PCIE_GBPS, "traffic": None,
-                    "note": "host-overhead bound (walk, plan, views, rebuild of 10k python objects), not link bound"},
+                    "note": "host-overhead bound (walk, plan, views, rebuild of 10k python objects), not link bound; the fastest of three timed "
+                            "blocks of 50 copies (a host-bound figure: other tenants of the box's CPU move it by 20 %)"},
           secondary={"inline_ms": t_in * 1e3, "background_ms": t_bg * 1e3, "inline_528_ms": t_in_s * 1e3,
                      "background_528_ms": t_bg_s * 1e3},
           cpu_baseline={"value": 1.0 / t_naive, "unit": "copies/s", "cores": 1, "kind": "port",
@@ -153,18 +161,22 @@ def config3():
         draw_polylines_multiscale(lane_maps, lanes, 256, 2, strides, clear=True)
 
     sync = torch.cuda.synchronize
-    t = _timeit(step, 50, 500, sync)
+    t = _best_of(step, 300, 500, sync)
 
-    def events_ms(fn, warm=50, iters=300):      # HIP events on the launch stream (torch's current stream)
-        for _ in range(warm):
-            fn()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(iters):
-            fn()
-        b.record()
-        sync()
-        return a.elapsed_time(b) / iters
+    def events_ms(fn, warm=100, iters=300):      # HIP events on the launch stream (torch's current stream); faster of two blocks
+        best = None
+        for _ in range(2):
+            for _ in range(warm):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            sync()
+            ms = a.elapsed_time(b) / iters
+            best = ms if best is None else min(best, ms)
+        return best
 
     t_boxes = events_ms(lambda: draw_heatmap_multiscale(maps, crb, brb, strides, 6.0, 1.0, clear=True)) * 1e-3
     t_lanes = events_ms(lambda: draw_polylines_multiscale(lane_maps, lanes, 256, 2, strides, clear=True)) * 1e-3
@@ -185,12 +197,13 @@ def config3():
         oracle.draw_heatmap_batched(hm, ci, r, sizes, clear=True, threads=threads)
     t_cpu = time.perf_counter() - t0
     return _line(metric="multi-scale target maps + lane raster (frames/s), 3840x2160 source, strides 4/8/16", value=B / t, unit="frames/s",
-          steps=500, warmup=50, ms_per_step=t * 1e3, dtype="f32",
+          steps=500, warmup=300, ms_per_step=t * 1e3, dtype="f32",
           config={"workload": "configs[3]: batch 32, box maps at strides 4/8/16 from float boxes (1 launch, draw_heatmap_multiscale) + "
                               "lane maps from 8 polylines x 24 points, 256 samples, radius 2 (2 launches, draw_polylines_multiscale)"},
           roofline={"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_GBPS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_GBPS,
                     "traffic": None, "algorithmic_bytes": nbytes,
-                    "note": "three launches over 87 MB of maps: launch / cull bound, far below the HBM roof by construction"},
+                    "note": "three launches over 2 x 87 MB of maps (box maps + lane maps); the faster of two timed blocks of 500 steps, each behind "
+                            "300 warm-up steps"},
           secondary={"box_maps_only_ms": t_boxes * 1e3, "box_maps_only_frames_per_s": B / t_boxes,
                      "box_maps_only_frac": map_bytes / t_boxes / 1e9 / HBM_GBPS,
                      "lane_raster_only_ms": t_lanes * 1e3, "lane_raster_only_frac": map_bytes / t_lanes / 1e9 / HBM_GBPS,

@@ -1,10 +1,17 @@
 #!/bin/bash
 set -uo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
-OUT="$ROOT/gpurun_out/r03"
+OUT="$ROOT/gpurun_out/r03/final"
 mkdir -p "$OUT"
 cd "$ROOT"
-timeout -k 10 600 python -m pytest tests/test_lane_helpers.py tests/test_lane_raster_gpu.py tests/test_fuzz_gpu.py -m gpu -x -q > "$OUT/gpu_tests_19.log" 2>&1; rc=$?; echo "[r03] pytest rc=$rc $(tail -1 $OUT/gpu_tests_19.log)"
-[ $rc -eq 0 ] || { tail -60 "$OUT/gpu_tests_19.log"; exit 1; }
-timeout -k 10 300 python scripts/tails_probe.py accv-lab_amd/accvlab/_amd_native/libaccv_hip_prev.so > "$OUT/tails_probe4.log" 2>&1; echo "[r03] rc=$?"
-grep -E "polyline" "$OUT/tails_probe4.log"
+for i in 1 2; do
+python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_k20_$i.json" 2> "$OUT/bench_k20.err"; echo "[r03] bench k20 rc=$?"
+python bench.py > "$OUT/bench_$i.json" 2> "$OUT/bench.err"; echo "[r03] bench rc=$?"
+done
+python - <<'PY'
+import json, os
+out=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/r03/final/"
+for f in ("bench_k20_1.json","bench_1.json","bench_k20_2.json","bench_2.json"):
+    d=json.loads([l for l in open(out+f) if l.startswith("{")][-1]); r=d["roofline"]
+    print(f, round(d["value"]), "frac", round(r["frac"],4), round(r["frac_wall"],4), {k:round(v["value"],1) for k,v in d["secondary"]["configs"].items()}, round(d["secondary"]["configs_wall_s"],1))
+PY
