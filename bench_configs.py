@@ -183,6 +183,18 @@ def config3():
     k_lanes = nat.last_dispatch()
     map_bytes = sum(m.numel() * 4 for m in maps)
     nbytes = 2 * sum(m.numel() * 4 for m in maps)       # box maps + lane maps, every pixel written once
+    # HBM traffic per step from the committed PMC record of this workload — only while the lane splat still dispatches the
+    # same instantiation and grid (else null)
+    traffic, traffic_source = None, "profiles/r03_traffic_c3.json not present"
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic_c3.json")))
+        if rec.get("lane_dispatch") == k_lanes:
+            traffic = rec["hbm_bytes_per_step"]
+            traffic_source = f"profiles/r03_traffic_c3.json (rocprofv3 --pmc passes, commit {rec.get('commit')}); not measured in this run"
+        else:
+            traffic_source = f"profiles/r03_traffic_c3.json was taken on {rec.get('lane_dispatch')!r}, this run dispatched {k_lanes!r}"
+    except Exception:  # noqa: BLE001
+        pass
     # CPU baseline: the oracle on the integer box targets of the three scales (one pass over the batch)
     c_np, b_np, sizes = crb.tensor.cpu().numpy(), brb.tensor.cpu().numpy(), crb.sample_sizes.cpu().numpy()
     threads = oracle.max_threads()
@@ -201,7 +213,7 @@ def config3():
           config={"workload": "configs[3]: batch 32, box maps at strides 4/8/16 from float boxes (1 launch, draw_heatmap_multiscale) + "
                               "lane maps from 8 polylines x 24 points, 256 samples, radius 2 (2 launches, draw_polylines_multiscale)"},
           roofline={"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_GBPS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_GBPS,
-                    "traffic": None, "algorithmic_bytes": nbytes,
+                    "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": nbytes,
                     "note": "three launches over 2 x 87 MB of maps (box maps + lane maps); the faster of two timed blocks of 500 steps, each behind "
                             "300 warm-up steps"},
           secondary={"box_maps_only_ms": t_boxes * 1e3, "box_maps_only_frames_per_s": B / t_boxes,
