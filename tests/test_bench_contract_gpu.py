@@ -62,6 +62,8 @@ def test_bench_line_has_the_contract_fields(monkeypatch):
         assert name in line["config"]["workload"] and line["value"] > 0 and line["ms_per_step"] > 0
         assert line["roofline"]["bound"] in ("host", "pcie", "hbm") and line["cpu_baseline"]["value"] > 0
     assert cfg["configs[3]"]["secondary"]["lane_raster_only_ms"] > 0
+    c3 = cfg["configs[3]"]["roofline"]
+    assert c3["traffic"] is None or 0.9 * c3["algorithmic_bytes"] < c3["traffic"] < 1.2 * c3["algorithmic_bytes"], c3["traffic_source"]
     assert sec["configs_wall_s"] < 60
 
 

@@ -100,7 +100,8 @@ def test_mask_to_indices_all_kernel_variants(b, m, ragged):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("b,m,density", [(8, 65536, 0.1), (2, 262144, 0.5), (1, 8192, 0.0), (4, 12288, 1.0), (3, 16384, 0.4), (16, 70001, 0.03),
+@pytest.mark.parametrize("b,m,density", [(8, 65536, 0.1), (2, 262144, 0.5), (1, 8192, 0.0), (4, 12288, 1.0), (3, 16384, 0.4), (2, 9001, 0.3), (5, 16383, 0.7),
+                                         (16, 70001, 0.03),
                                          (64, 65536, 0.2), (1, 1048576, 0.01)])
 def test_segmented_mask_to_indices_one_pass_two_pass_and_graph_replay(b, m, density):
     """few, very wide rows: ONE launch
