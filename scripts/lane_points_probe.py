@@ -78,6 +78,16 @@ def main():
         return out
 
     full = torch.full((B,), n, dtype=torch.int32, device=dev)
+    if "--rule" in sys.argv:
+        # A/B build only: is the waves-per-tile rule (four waves only when coarse tiles are half of the launch) right for other
+        # stride sets than config 3's?
+        for strides in ((4.0, 8.0, 16.0), (4.0, 16.0), (4.0, 8.0), (8.0, 16.0), (2.0, 8.0), (2.0, 32.0), (16.0, 32.0), (8.0,), (2.0,)):
+            row = {"strides": strides}
+            for name, nw in (("rule", -1), ("one wave", 1), ("four waves", 4)):
+                nat.tune_set("pts_nw", nw)
+                row[name] = run(strides, full, 2)["shipped"]["us"]
+            print(json.dumps(row))
+        return
     if "--sweep" in sys.argv:
         # A/B build only (make -C accv-lab_amd/csrc tune; ACCV_HIP_LIB=.../libaccv_hip_tune.so): per-scale mode of the point splat
         none_ = torch.zeros(B, dtype=torch.int32, device=dev)

@@ -1,23 +1,9 @@
 #!/bin/bash
 set -uo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
-OUT="$ROOT/gpurun_out/r03/c3_traffic"
+OUT="$ROOT/gpurun_out/r03"
 mkdir -p "$OUT"
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- python3 "$ROOT/scripts/bench_configs.py" 3 > "$OUT/line_write.json" 2> "$OUT/write.err"; echo "[r03] write rc=$?"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- python3 "$ROOT/scripts/bench_configs.py" 3 > "$OUT/line_fetch.json" 2> "$OUT/fetch.err"; echo "[r03] fetch rc=$?"
-python3 - <<'PY'
-import csv, collections, glob, os, json
-out=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/r03/c3_traffic/"
-res={}
-for sub,counter in (("write","WRITE_SIZE"),("fetch","FETCH_SIZE")):
-    f=glob.glob(out+sub+"/**/*counter_collection.csv", recursive=True)[0]
-    agg=collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"]==counter and any(k in r["Kernel_Name"] for k in ("splat_multi_kernel","splat_points_multi_kernel","polyline_kernel")):
-            agg[r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0].replace("void ","")].append(float(r["Counter_Value"]))
-    for k,v in agg.items():
-        res.setdefault(k,{})[counter+"_KB"]=sum(v)/len(v); res[k]["launches"]=len(v)
-print(json.dumps(res, indent=1))
-json.dump(res, open(out+"summary.json","w"), indent=1)
-PY
+cd "$ROOT"
+ACCV_HIP_LIB=$ROOT/accv-lab_amd/accvlab/_amd_native/libaccv_hip_tune.so timeout -k 10 300 python scripts/lane_points_probe.py --rule > "$OUT/lane_probe_rule.log" 2>&1; echo "[r03] rc=$?"
+cat "$OUT/lane_probe_rule.log"
+timeout -k 10 300 python -m pytest tests/test_bool_indexing_bound.py tests/test_bench_contract_gpu.py -m gpu -q 2>&1 | tail -2
