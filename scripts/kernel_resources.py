@@ -12,7 +12,7 @@ flt = sys.argv[2] if len(sys.argv) > 2 else ""
 cs = os.path.join(ROOT, "accv-lab_amd", "csrc")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-I{ROOT}/include", f"-I{cs}",
        "-fno-gpu-rdc", "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(cs, src), "-o", "/dev/null"] + \
-      (["-DACCV_TUNE_BUILD"] if os.environ.get("TUNE") else [])
+      (["-DACCV_TUNE_BUILD"] if os.environ.get("TUNE") else []) + os.environ.get("EXTRA_DEFS", "").split()
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
 rows = {}
