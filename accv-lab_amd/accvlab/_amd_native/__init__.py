@@ -27,6 +27,7 @@ HM_TILE_ROWS_16 = 32
 HM_TILE_ROWS_8 = 64
 HM_CALLER_SCALE_ORDER = 256
 HM_PLAIN_STORES = 128
+HM_POINT_COUNTS_I64 = 512
 MP_IDX_I64 = 1
 MP_COUNTS_I64 = 2
 MP_LABELS_I64 = 4
@@ -53,6 +54,8 @@ SIGNATURES = {
     "accv_draw_heatmap_multiscale_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _f, _f, _u, _vp]),
     "accv_draw_points_workspace_bytes": (_sz, [_i, _i]),
     "accv_draw_points_multiscale_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _f, _f, _u, _vp, _sz, _vp]),
+    "accv_draw_polylines_fused_applicable": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
+    "accv_draw_polylines_multiscale_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _f, _f, _u, _vp]),
     "accv_heatmap_targets_from_boxes_f32": (_i, [_vp, _vp, _ll, _f, _vp, _vp, _vp]),
     "accv_heatmap_targets_from_points_f32": (_i, [_vp, _ll, _f, _i, _vp, _vp, _vp]),
     # H2 ragged kernels

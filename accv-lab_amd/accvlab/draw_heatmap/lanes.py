@@ -14,6 +14,7 @@ import ctypes
 from types import SimpleNamespace
 from typing import Optional
 
+import numpy as np
 import torch
 
 from .. import _amd_native as _nat
@@ -38,6 +39,16 @@ def _cached(key, make):
             _cache.clear()
         _cache[key] = t
     return t
+
+
+def _fraction_rows(rows: int, num_samples: int, dev) -> torch.Tensor:
+    """Arc-length fractions of the samples, one row per polyline: k / (num_samples - 1) in IEEE float32 (computed on the host so
+    that the fused lane raster, which forms the same quotient inside its kernel, lands on the same samples bit for bit)."""
+    if num_samples > 1:
+        row = np.arange(num_samples, dtype=np.float32) / np.float32(num_samples - 1)
+    else:
+        row = np.zeros(1, np.float32)
+    return torch.from_numpy(row).to(dev).unsqueeze(0).expand(rows, num_samples).contiguous()
 
 
 def sample_lane_targets(polylines: torch.Tensor, num_samples: int, radius: int, out_size_factor: float = 1.0, *,
@@ -69,9 +80,7 @@ def sample_lane_targets(polylines: torch.Tensor, num_samples: int, radius: int, 
     if b * l == 0:
         return centers, radii
     # arc-length fractions 0..1, one row per lane (a cached constant: no per-call kernel)
-    frac = _cached(("frac", b * l, num_samples, dev), lambda: torch.linspace(
-        0.0, 1.0, num_samples, device=dev).unsqueeze(0).expand(b * l, num_samples).contiguous()
-        if num_samples > 1 else torch.zeros((b * l, 1), device=dev))
+    frac = _cached(("frac", b * l, num_samples, dev), lambda: _fraction_rows(b * l, num_samples, dev))
     samples = _poly._gpu(pts, frac, counts, None, True, True, False)[0]
     with _nat.device_guard(dev):
         _nat.check(_nat.lib().accv_heatmap_targets_from_points_f32(
@@ -150,12 +159,49 @@ def sample_lanes(polylines: torch.Tensor, num_samples: int, *, num_points: Optio
             raise RuntimeError("num_points must be of shape [batch, lanes] on the polylines' device")
         _poly._check_sizes(num_points.reshape(-1), p, "num_points")
         counts = num_points.contiguous().view(b * l)
-    frac = _cached(("frac", b * l, num_samples, dev), lambda: torch.linspace(
-        0.0, 1.0, num_samples, device=dev).unsqueeze(0).expand(b * l, num_samples).contiguous()
-        if num_samples > 1 else torch.zeros((b * l, 1), device=dev))
+    frac = _cached(("frac", b * l, num_samples, dev), lambda: _fraction_rows(b * l, num_samples, dev))
     samples = _poly._gpu(polylines.contiguous().view(b * l, p, 2), frac, counts, None, True, True, False,
                          group_boxes_ptr)[0]
     return samples.view(b, l * num_samples, 2)
+
+
+# the fused kernel (sampling inside the tile waves) for the shapes it takes; False = always sampler + point splat (the tests
+# compare the two bit for bit)
+FUSED_SAMPLER = True
+
+
+def _draw_polylines_fused(heatmaps, hs, ws_, strides, polylines, num_samples, radius, diameter_to_sigma_factor, k_scale,
+                          num_points, num_lanes, clear):
+    b, l, p, _ = polylines.shape
+    dev = polylines.device
+    pts = polylines.contiguous()
+    counts = None
+    if num_points is not None:
+        if not (num_points.shape == (b, l) and num_points.device == dev):
+            raise RuntimeError("num_points must be of shape [batch, lanes] on the polylines' device")
+        _poly._check_sizes(num_points.reshape(-1), p, "num_points")
+        counts = num_points.contiguous().view(b * l)
+        if counts.dtype not in (torch.int32, torch.int64):
+            counts = counts.to(torch.int64)
+    if num_lanes is None:
+        lanes = _cached(("full", b, l, dev), lambda: torch.full((b,), l, dtype=torch.int32, device=dev))
+    else:
+        if not (num_lanes.shape == (b,)):
+            raise RuntimeError("num_lanes must be of shape [batch]")
+        lanes = num_lanes.contiguous()
+        if lanes.dtype not in (torch.int32, torch.int64):
+            lanes = lanes.to(torch.int64)
+    k = len(heatmaps)
+    ptrs = (ctypes.c_void_p * k)(*[hm.data_ptr() for hm in heatmaps])
+    st = (ctypes.c_float * k)(*strides)
+    flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if lanes.dtype == torch.int64 else 0) | \
+        (_nat.HM_POINT_COUNTS_I64 if counts is not None and counts.dtype == torch.int64 else 0) | _ops._FORCED_FLAGS
+    with _nat.device_guard(dev):
+        status = _nat.lib().accv_draw_polylines_multiscale_f32(
+            ptrs, hs, ws_, st, k, b, pts.data_ptr(), l, p, counts.data_ptr() if counts is not None else None,
+            lanes.data_ptr(), int(num_samples), int(radius), float(diameter_to_sigma_factor), float(k_scale), flags,
+            _nat.stream_ptr(dev))
+    _nat.check(status, "draw_polylines_multiscale")
 
 
 def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: int, radius: int, out_size_factors,
@@ -187,6 +233,15 @@ def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: in
     n = l * num_samples
     dev = polylines.device
     lib = _nat.lib()
+    k = len(heatmaps)
+    hs = (ctypes.c_int * k)(*[hm.size(1) for hm in heatmaps])
+    ws_ = (ctypes.c_int * k)(*[hm.size(2) for hm in heatmaps])
+    if FUSED_SAMPLER and b * l > 0 and polylines.dtype == torch.float32 and polylines.dim() == 4 and \
+            lib.accv_draw_polylines_fused_applicable(hs, ws_, k, b, l, polylines.size(2), num_samples):
+        # ONE launch: the tile waves sample the polylines themselves (no sampler launch, no sample buffer)
+        _draw_polylines_fused(heatmaps, hs, ws_, strides, polylines, num_samples, radius, diameter_to_sigma_factor, k_scale,
+                              num_points, num_lanes, clear)
+        return
     with _nat.device_guard(dev):
         nbytes = lib.accv_draw_points_workspace_bytes(b, n)
         work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -202,10 +257,7 @@ def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: in
         sizes = num_lanes.clamp(0, l) * num_samples
         if sizes.dtype not in (torch.int32, torch.int64):
             sizes = sizes.to(torch.int64)
-    k = len(heatmaps)
     ptrs = (ctypes.c_void_p * k)(*[hm.data_ptr() for hm in heatmaps])
-    hs = (ctypes.c_int * k)(*[hm.size(1) for hm in heatmaps])
-    ws_ = (ctypes.c_int * k)(*[hm.size(2) for hm in heatmaps])
     st = (ctypes.c_float * k)(*strides)
     flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if sizes.dtype == torch.int64 else 0) | \
         (_nat.HM_GROUP_BOXES_GIVEN if boxes_by_sampler else 0) | _ops._FORCED_FLAGS

@@ -32,6 +32,7 @@
 #include <cstring>
 
 #include "accv_common.h"
+#include "polyline_arith.h"
 
 namespace {
 
@@ -809,6 +810,308 @@ __global__ __launch_bounds__(NW * 64) void splat_points_multi_kernel(const Multi
     small_body<CLEAR, SM, 2, NW, TH>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s], s_hit, s_tile);
 }
 
+// ---------------------------------------------------------------- fused lane raster: polylines -> maps, ONE launch
+// The two-launch lane raster above reads samples that polyline_kernel wrote in a launch of its own (5.9 us of configs[3]'s 30 us:
+// a 4.4 us launch floor and a chain of its own, during which the chip idles).  Here the tile wave works from the POLYLINES:
+//   level 1: every lane takes one segment of the frame's polylines (a frame's L x P2 point slots, P2 = points per polyline
+//            rounded up to a power of two, at most 64 in all) and tests its bounding box against the tile — what the
+//            group boxes of the sampler did, with no launch in front and nothing to read but the points themselves;
+//   level 2: for the polylines with a segment in reach (most tiles: none) the wave repeats the sampler's arithmetic — segment
+//            lengths, the prefix sum in the sampler's own order of additions (all polylines of a round of 64 slots at once,
+//            each in its block of P2 lanes), and, for the stretch of samples that falls on the segments in reach, binary
+//            search + interpolation — with the accumulated distances and the points in registers (DPP / ds_bpermute instead
+//            of LDS arrays), converts the samples to this scale's pixels and splats them through the same hit list / row walk
+//            / write-back as splat_points_multi_kernel.
+// Bit-identical to sampler + point splat (tests/test_lane_raster_fused_gpu.py): the float steps are shared with
+// polyline_kernel through polyline_arith.h, the scan follows polyline_kernel<f32, 256>'s order for polylines of at most 64
+// points (one segment per thread, totals of four neighbours summed left to right, Hillis-Steele scan of the at most 16
+// totals, exclusive offset = inclusive - own, offsets of the four neighbours added left to right), the samples sit at the
+// fractions k / (S - 1) (IEEE division; the python layer builds the sampler's table the same way), and every sample that can
+// land in the tile is evaluated: a sample lies on the segment its binary search finds, inside that segment's bounding box
+// (weights in [0, 1]; the tile's reach is widened by a source pixel for the rounding of the products, and a segment with a
+// coordinate of 2^20 or more, where that pixel would not cover it, counts as in reach), so it belongs to a segment in reach,
+// and the stretch of sample numbers taken from the accumulated distances of the first and last such segment is widened by
+// two samples either side (a polyline whose length is zero or not finite is evaluated whole).
+// Where it pays (scripts/lane_fused_probe.py, profiles/r03_lane_raster_fused_*.log; configs[3]'s maps, 256 samples, radius 2):
+// the sampling is repeated in every tile a polyline's segments reach, at every scale — VALU work of a wave that the two-launch
+// path spends once, in the sampler — so the launch saved pays for sparse lane sets only: 1 / 2 polylines of 24 points per frame
+// 22.6 / 24.2 -> 17.8 / 18.6 us (0.61 / 0.59 of the HBM peak), one of 64 points 23.1 -> 17.2 us; 4 x 16 points ties (24.5 vs
+// 25.1 us) and configs[3]'s own 8 x 24 points — four rounds of 64 slots, most stride-4 tiles in reach of a polyline — took
+// 40 us against 30 us (the code below keeps its loops over rounds; kLaneRounds = 4 is that variant, bit-identical as well).
+// fused_lane_shape() therefore admits one round of slots and segments that carry at most half a pass of samples each.
+constexpr int kLaneRounds = 1;   // rounds of 64 point slots per frame
+struct LaneParams {
+    const float2* points;       // [B, L, P] source pixels
+    const void* point_counts;   // [B * L] valid leading points per polyline (i32 / i64), null = P
+    int L, P, S;
+    int p2_shift;               // point slots per polyline = 1 << p2_shift >= P
+    int counts_i64;
+};
+struct FusedLaneParams {
+    MultiParams mp;             // per scale: hm, H, W, stride, radius, factor, k, tiles; counts = valid polylines per frame, n_max = L
+    LaneParams lp;
+};
+
+// data-parallel-primitive moves (gfx9 DPP controls); lanes without a source lane keep `old`
+constexpr int kDppQuad0 = 0x00, kDppQuad1 = 0x55, kDppQuad2 = 0xAA, kDppQuad3 = 0xFF;   // broadcast lane 0..3 of every quad
+constexpr int kDppRowShr = 0x110;                                                      // + n: lane i <- lane i - n inside rows of 16
+constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;                              // lane i <- lane i + 1 / i - 1, whole wave
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float old, float src)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float lane_read(float v, int src_lane)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+template <typename T, int N>
+__device__ __forceinline__ T pick(int r, const T (&a)[N])   // a[r] for a wave-uniform r without indexing registers
+{
+    T v = a[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) v = r == i ? a[i] : v;
+    return v;
+}
+
+template <bool CLEAR, int SM>
+__device__ __forceinline__ void lane_body(const SplatParams& p, const LaneParams& lp, long long linear_group, Hit* s_hit,
+                                          SmallTile s_tile)
+{
+    constexpr int TW = kSmallTW, TH = kSmallTH, RPW = TH / 2;
+    const int lane = threadIdx.x & 63;
+    TileCtx t;
+    if (!locate_tile<TW, TH, 1>(p, 0, t, linear_group)) return;   // t.n = valid polylines of this frame (<= L)
+    const int sub = lane >> 5, col0 = t.tx0 + (lane & 31) * 4, row0 = sub * RPW;
+    float* plane_ptr = p.hm + (size_t)t.plane * (size_t)p.H * (size_t)p.W;
+
+    const float init = CLEAR ? 0.0f : -__builtin_inff();
+    vfloat4 vinit = vfloat4{init, init, init, init};
+    asm volatile("" : "+v"(vinit));
+    bool tile_ready = false;
+    auto prepare_tile = [&]() {   // on first use, as small_body
+        if (tile_ready) return;
+        tile_ready = true;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) *reinterpret_cast<vfloat4*>(&s_tile[row0 + i][(lane & 31) * 4]) = vinit;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    const int sh = lp.p2_shift, P2 = 1 << sh, per_round = 64 >> sh;
+    const unsigned long long p2_mask = P2 == 64 ? ~0ull : ((1ull << P2) - 1ull);
+    const int rc = min(max(t.radius, 0), 1 << 30);
+    const int rows_hint = 2 * min(rc, 64) + 1;
+    ReachBounds rb = reach_bounds(t, rc, t.tx0, t.tx1, t.ty0, t.ty1);
+    rb.xlo -= 1.0f;   // the interpolation's products round: a sample can leave its segment's box by 4e-7 of the coordinates
+    rb.ylo -= 1.0f;
+    rb.xhi += 1.0f;
+    rb.yhi += 1.0f;
+    const float2* pts = lp.points + (size_t)t.plane * (size_t)lp.L * (size_t)lp.P;
+    const int j = lane & (P2 - 1), lb = lane - j;
+
+    // ---- level 1: the frame's point slots, all rounds requested together; one segment per lane
+    float qx[kLaneRounds], qy[kLaneRounds];
+    int cn[kLaneRounds];
+#pragma unroll
+    for (int r = 0; r < kLaneRounds; ++r) {
+        qx[r] = qy[r] = 0.0f;
+        cn[r] = 0;
+        if (r * per_round < lp.L) {   // uniform
+            const int l = (r * 64 + lane) >> sh, lc = min(l, lp.L - 1);
+            const float2 v = pts[(size_t)lc * lp.P + min(j, lp.P - 1)];
+            qx[r] = v.x;
+            qy[r] = v.y;
+            int c = lp.P;
+            if (lp.point_counts) {
+                const long long at = t.plane * lp.L + lc;
+                const long long c64 = lp.counts_i64 ? static_cast<const long long*>(lp.point_counts)[at]
+                                                    : (long long)static_cast<const int*>(lp.point_counts)[at];
+                c = (int)max(0ll, min((long long)lp.P, c64));
+            }
+            cn[r] = l < t.n ? c : 0;   // a polyline past the frame's count has no points
+        }
+    }
+    unsigned long long mseg[kLaneRounds];   // per round: the segments that can reach the tile (wave-uniform)
+    float nx[kLaneRounds], ny[kLaneRounds];  // point j + 1 of the lane's polyline (point j itself for a single point)
+    bool any_round = false;
+#pragma unroll
+    for (int r = 0; r < kLaneRounds; ++r) {
+        mseg[r] = 0;
+        nx[r] = ny[r] = 0.0f;
+        if (r * per_round < lp.L) {
+            const int n = cn[r];
+            const bool has_next = j + 1 < n;
+            nx[r] = dpp_f<kDppWaveShl1>(qx[r], qx[r]);   // (the last slot of a polyline never starts a segment)
+            ny[r] = dpp_f<kDppWaveShl1>(qy[r], qy[r]);
+            if (!has_next) {
+                nx[r] = qx[r];
+                ny[r] = qy[r];
+            }
+            const bool seg = has_next || (n == 1 && j == 0);
+            const float ext = fmaxf(fmaxf(fabsf(qx[r]), fabsf(qy[r])), fmaxf(fabsf(nx[r]), fabsf(ny[r])));
+            const bool reach = fmaxf(qx[r], nx[r]) >= rb.xlo && fminf(qx[r], nx[r]) < rb.xhi &&
+                               fmaxf(qy[r], ny[r]) >= rb.ylo && fminf(qy[r], ny[r]) < rb.yhi;
+            mseg[r] = __ballot(seg && (reach || !(ext < 1048576.0f)));
+            any_round = any_round || mseg[r] != 0;
+        }
+    }
+
+    int list_n = 0;   // hits waiting in s_hit
+    if (any_round) {
+        // ---- level 2a: accumulated distances of the polylines of every round with a segment in reach (the rounds' chains
+        // of lane exchanges are independent and overlap), and each polyline's stretch of sample numbers
+        float acc[kLaneRounds], tot[kLaneRounds];
+        int klo[kLaneRounds], khi[kLaneRounds];
+        const float s1 = (float)(lp.S - 1);
+#pragma unroll
+        for (int r = 0; r < kLaneRounds; ++r) {
+            acc[r] = tot[r] = 0.0f;
+            klo[r] = 1;
+            khi[r] = 0;
+            if (mseg[r] != 0) {   // uniform
+                const int n = cn[r];
+                float len = 0.0f;   // polyline_kernel: diff = point[s] - point[s + 1], acc = fma(diff, diff, acc) per coordinate, sqrt
+                if (j + 1 < n)
+                    len = sqrtf(accv_poly::seg_length2_step(accv_poly::seg_length2_step(0.0f, qx[r] - nx[r]), qy[r] - ny[r]));
+                const float v0 = dpp_f<kDppQuad0>(len, len), v1 = dpp_f<kDppQuad1>(len, len), v2 = dpp_f<kDppQuad2>(len, len),
+                            v3 = dpp_f<kDppQuad3>(len, len);
+                const float chunk = ((v0 + v1) + v2) + v3;
+                const float total4 = lane_read(chunk, lb + ((j << 2) & (P2 - 1)));   // (every lane takes part in the exchange)
+                const float own = j < (P2 >> 2) ? total4 : 0.0f;
+                float incl = own;   // lanes j < P2 / 4 <= 16 of the block hold its totals; they sit in one row of 16
+                {
+                    float up = dpp_f<kDppRowShr + 1>(0.0f, incl);
+                    if (j >= 1) incl += up;
+                    up = dpp_f<kDppRowShr + 2>(0.0f, incl);
+                    if (j >= 2) incl += up;
+                    up = dpp_f<kDppRowShr + 4>(0.0f, incl);
+                    if (j >= 4) incl += up;
+                    up = dpp_f<kDppRowShr + 8>(0.0f, incl);
+                    if (j >= 8) incl += up;
+                }
+                const float excl = incl - own;
+                float base = lane_read(excl, lb + (j >> 2));
+                const int u4 = j & 3;
+                if (u4 >= 1) base += v0;
+                if (u4 >= 2) base += v1;
+                if (u4 >= 3) base += v2;
+                const float acc_next = base != 0.0f ? len + base : len;   // accum[j + 1]
+                const float up1 = dpp_f<kDppWaveShr1>(0.0f, acc_next);
+                acc[r] = j == 0 ? 0.0f : up1;                             // accum[j], valid for j < n
+                tot[r] = lane_read(acc[r], lb + max(n - 1, 0));
+                // the block's segments in reach -> its stretch of sample numbers
+                const unsigned long long pm = (mseg[r] >> lb) & p2_mask;
+                if (pm != 0) {
+                    klo[r] = 0;
+                    khi[r] = lp.S - 1;
+                }
+                const int jf = pm ? __builtin_ctzll(pm) : 0, jl = pm ? 63 - __builtin_clzll(pm) : 0;
+                const float d_lo = lane_read(acc[r], lb + jf), d_hi = lane_read(acc[r], lb + min(jl + 1, max(n - 1, 0)));
+                if (pm != 0 && tot[r] > 0.0f && tot[r] < __builtin_inff()) {
+                    const float inv = __builtin_amdgcn_rcpf(tot[r]) * s1;   // (approximate: the stretch is widened by two samples)
+                    klo[r] = max(0, (int)floorf(d_lo * inv) - 2);
+                    khi[r] = min(lp.S - 1, (int)ceilf(d_hi * inv) + 2);
+                }
+            }
+        }
+        // ---- level 2b: the samples, a round of 64 slots at a time, P2 samples per polyline and pass
+#pragma unroll 1
+        for (int r = 0; r < kLaneRounds; ++r) {
+            if (pick(r, mseg) == 0) continue;
+            const float A = pick(r, acc), total = pick(r, tot), ax = pick(r, qx), ay = pick(r, qy);
+            const int n = pick(r, cn), k_lo = pick(r, klo), k_hi = pick(r, khi);
+            for (int k0 = k_lo + j;; k0 += P2) {
+                const bool act = k0 <= k_hi;
+                if (__ballot(act) == 0) break;
+                const int k = min(k0, lp.S - 1);
+                const float frac = lp.S > 1 ? __fdiv_rn((float)k, s1) : 0.0f;
+                const float d = accv_poly::scale_query(frac, total);
+                // last point whose accumulated distance is <= d (polyline_kernel; all lanes stay in the loop for the exchanges)
+                int mn = 0, mx = max(n - 1, 0);
+                while (__ballot(act && mx - mn > 1)) {
+                    const int c = (mx + mn) >> 1;
+                    const float v = lane_read(A, lb + c);
+                    if (mx - mn > 1) {
+                        if (v < d) mn = c;
+                        else if (v > d) mx = c;
+                        else mn = mx = c;
+                    }
+                }
+                int idx = mn;
+                if (0.0f > d) idx = -1;
+                else if (total < d) idx = n - 1;
+                const int ia = min(max(idx, 0), max(n - 1, 0)), ic = min(ia + 1, max(n - 1, 0));
+                const float d0 = lane_read(A, lb + ia), d1 = lane_read(A, lb + ic);
+                const float pax = lane_read(ax, lb + ia), pay = lane_read(ay, lb + ia);
+                const float pcx = lane_read(ax, lb + ic), pcy = lane_read(ay, lb + ic);
+                float sx = pax, sy = pay;   // before the first / beyond the last point, or a segment shorter than epsilon
+                if (idx >= 0 && idx < n - 1) {
+                    const float seg_len = d1 - d0;
+                    if (seg_len >= 1.1920928955078125e-07f) {
+                        float w0, w1;
+                        accv_poly::lerp_weights(d, d0, d1, seg_len, w0, w1);
+                        sx = accv_poly::lerp_coord(pax, w0, pcx, w1);
+                        sy = accv_poly::lerp_coord(pay, w0, pcy, w1);
+                    }
+                }
+                // sample -> target of this scale (cull_load<2>), runs of samples on one pixel are one splat
+                Cand c{(int)__fdiv_rn(sx, t.stride), (int)__fdiv_rn(sy, t.stride), t.radius, 0};
+                if ((sx != sx) || (sy != sy) || !act) c = Cand{0, 0, -1, 0};
+                const int ux = dpp_i<kDppWaveShr1>(0, c.x), uy = dpp_i<kDppWaveShr1>(0, c.y), ur = dpp_i<kDppWaveShr1>(-1, c.r);
+                if (j > 0 && ux == c.x && uy == c.y && ur == c.r) c.r = -1;
+                constexpr int kClampXY = 1 << 29, kClampR = 1 << 30;   // the conservative 32-bit test of cull_test
+                const int xc = min(max(c.x, -kClampXY), kClampXY), yc = min(max(c.y, -kClampXY), kClampXY);
+                const int rr = min(c.r, kClampR);
+                const bool in = c.r >= 0 && xc - rr < t.tx1 && xc + rr >= t.tx0 && yc - rr < t.ty1 && yc + rr >= t.ty0;
+                const unsigned long long m = __ballot(in);
+                const int nh = __popcll(m);
+                if (nh == 0) continue;
+                prepare_tile();
+                if (list_n + nh > kCand) {   // no room: walk what is waiting first
+                    walk_hits<false>(p, t, lane, list_n, s_hit, s_tile, rows_hint);
+                    list_n = 0;
+                }
+                if (in) s_hit[list_n + __popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, c.x, c.y, c.r);
+                list_n += nh;
+            }
+        }
+        if (list_n > 0) walk_hits<false>(p, t, lane, list_n, s_hit, s_tile, rows_hint);
+    }
+
+    if (!tile_ready) {   // nothing reached the tile: fused clear = zeros, in place = no HBM traffic at all
+        if constexpr (CLEAR) {
+            if (col0 < p.W) {
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    const int row = t.ty0 + row0 + i;
+                    if (row < p.H) store_segment<SM>(p, plane_ptr, row, col0, vfloat4{0.0f, 0.0f, 0.0f, 0.0f});
+                }
+            }
+        }
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // all atomics landed before the tile is read back
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (col0 >= p.W) return;
+    write_back_rows<CLEAR, SM, RPW>(p, t, plane_ptr, s_tile, row0, lane, col0);
+}
+
+template <bool CLEAR, int SM>
+__global__ __launch_bounds__(64) void lane_raster_multi_kernel(const FusedLaneParams fp)
+{
+    __shared__ Hit s_hit[kCand];
+    __shared__ __attribute__((aligned(16))) float s_tile[kSmallTH][kSmallLdsW];
+    int s = 0;
+    while (s + 1 < fp.mp.n_scales && (long long)blockIdx.x >= fp.mp.tile_begin[s + 1]) ++s;
+    lane_body<CLEAR, SM>(fp.mp.scale[s], fp.lp, (long long)blockIdx.x - fp.mp.tile_begin[s], s_hit, s_tile);
+}
+
 // bounding box (xmin, ymin, xmax, ymax) of every 64 consecutive points of points[b, :, :] (NaN points ignored; a group
 // without valid points keeps xmin = +inf > xmax = -inf): one wave per group
 __global__ __launch_bounds__(64) void group_boxes_kernel(const float2* __restrict__ points, int num_points, int n_groups,
@@ -1502,6 +1805,135 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
 #undef ACCV_LAUNCH_POINTS
     note_dispatch("splat_points_multi_kernel", 4, 8, clear, nt >= 2 ? 4 : 0, grid, block);
     return accv::check_launch("draw_heatmap multi-scale point splat kernel");
+}
+
+// shape rule of the fused lane raster (one place: the entry point below and accv_draw_polylines_fused_applicable)
+namespace {
+struct FusedLaneShape {
+    bool ok;
+    int p2_shift;
+};
+FusedLaneShape fused_lane_shape(const int* heights, const int* widths, int num_scales, int batch, int lanes, int points,
+                                int num_samples)
+{
+    FusedLaneShape out{false, 0};
+    if (lanes < 1 || points < 1 || points > 64 || num_samples < 1 || num_samples > (1 << 20) || batch < 1) return out;
+    int sh = 2;   // at least four slots per polyline: the polylines in reach are a 64-bit mask
+    while ((1 << sh) < points) ++sh;
+    if (((long long)lanes << sh) > kLaneRounds * 64) return out;
+    // a pass evaluates 2^sh samples per polyline: more than a pass or two per segment in reach (few, long segments carrying many
+    // samples: 8 polylines x 8 points x 256 samples 42 us against 30 us) and the sampler launch is the cheaper way
+    if ((long long)num_samples * 2 > (long long)std::max(points - 1, 1) << sh) return out;
+    // one wave per tile only: launches that the point splat would run with four waves per tile (coarse scales are at least
+    // half of the tiles) stay on the two-launch path
+    long long tiles = 0, coarse = 0;
+    for (int i = 0; i < num_scales; ++i) {
+        if (heights[i] <= 0 || widths[i] <= 0) continue;
+        const long long nt = (long long)batch * ((widths[i] + 127) / 128) * ((heights[i] + 15) / 16);
+        tiles += nt;
+        if ((double)batch * lanes * num_samples >= 24.0 * (double)nt) coarse += nt;
+    }
+    if (tiles == 0 || 2 * coarse >= tiles) return out;
+    out.ok = true;
+    out.p2_shift = sh;
+    return out;
+}
+}  // namespace
+
+int accv_draw_polylines_fused_applicable(const int* heights, const int* widths, int num_scales, int batch, int lanes,
+                                         int points, int num_samples)
+{
+    if (!heights || !widths || num_scales < 1 || num_scales > kMaxScales) return 0;
+    if (accv::tune_get("lane_fused", 1) == 0) return 0;   // A/B build only
+    return fused_lane_shape(heights, widths, num_scales, batch, lanes, points, num_samples).ok ? 1 : 0;
+}
+
+int accv_draw_polylines_multiscale_f32(float* const* heatmaps, const int* heights, const int* widths, const float* strides,
+                                       int num_scales, int batch, const float* polylines_xy, int lanes, int points,
+                                       const void* point_counts, const void* lane_counts, int num_samples, int radius,
+                                       float diameter_to_sigma_factor, float k_scale, unsigned flags, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (num_scales < 1 || num_scales > kMaxScales)
+        return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: 1..%d scales supported, got %d", kMaxScales, num_scales);
+    if (!heatmaps || !heights || !widths || !strides) return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: null array");
+    if (batch < 0) return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: negative batch");
+    if (batch == 0) return ACCV_OK;
+    if (radius < 0) return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: negative radius");
+    const FusedLaneShape shape = fused_lane_shape(heights, widths, num_scales, batch, lanes, points, num_samples);
+    if (!shape.ok)
+        return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: shape outside the fused kernel (1..64 points per polyline, "
+                                       "lanes x points rounded up to a power of two <= %d, samples <= (points - 1) x that power "
+                                       "of two / 2, fine scales in the majority: accv_draw_polylines_fused_applicable); use "
+                                       "accv_polyline_sample_boxes + accv_draw_points_multiscale_f32", kLaneRounds * 64);
+    if (!polylines_xy || !lane_counts)
+        return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: null polylines / lane_counts");
+    if (reinterpret_cast<uintptr_t>(polylines_xy) & 7u)
+        return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: polylines need 8-byte alignment");
+    const bool clear = (flags & ACCV_HM_CLEAR) != 0;
+
+    FusedLaneParams fp{};
+    MultiParams& mp = fp.mp;
+    long long tiles = 0;
+    int used = 0;
+    for (int i = 0; i < num_scales; ++i) {
+        if (int rc = check_common(heatmaps[i], heights[i], widths[i], diameter_to_sigma_factor, "draw_polylines_multiscale"))
+            return rc;
+        if (!(strides[i] > 0.0f)) return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: stride %d is not positive", i);
+        if (heights[i] == 0 || widths[i] == 0) continue;
+        if (!heatmaps[i]) return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: heatmap %d is null", i);
+        if (widths[i] % 4 != 0 || (reinterpret_cast<uintptr_t>(heatmaps[i]) & 15u) ||
+            (size_t)heights[i] * widths[i] * sizeof(float) >= ((size_t)1 << 31))
+            return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: map %d needs a width that is a multiple of 4, a 16-byte "
+                                           "aligned base and planes below 2 GiB", i);
+        SplatParams& p = mp.scale[used];
+        p.hm = heatmaps[i];
+        p.counts = lane_counts;
+        p.H = heights[i];
+        p.W = widths[i];
+        p.n_max = lanes;
+        p.factor = diameter_to_sigma_factor;
+        p.k = k_scale;
+        p.counts_i64 = (flags & ACCV_HM_COUNTS_I64) ? 1 : 0;
+        p.stride = strides[i];
+        p.radius = radius;
+        p.n_groups = 0;
+        p.tiles_x = (p.W + 127) / 128;
+        p.tiles_y = (p.H + 15) / 16;
+        p.n_tiles = (long long)batch * p.tiles_x * p.tiles_y;
+        p.grid3d = 0;
+        mp.tile_begin[used] = tiles;
+        tiles += p.n_tiles;
+        ++used;
+    }
+    mp.n_scales = used;
+    mp.tile_begin[used] = tiles;
+    if (used == 0 || tiles == 0) return ACCV_OK;
+    if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: %lld tiles exceed the grid limit", tiles);
+    if (!(flags & ACCV_HM_CALLER_SCALE_ORDER)) coarse_scales_first(mp);
+    fp.lp.points = reinterpret_cast<const float2*>(polylines_xy);
+    fp.lp.point_counts = point_counts;
+    fp.lp.L = lanes;
+    fp.lp.P = points;
+    fp.lp.S = num_samples;
+    fp.lp.p2_shift = shape.p2_shift;
+    fp.lp.counts_i64 = (flags & ACCV_HM_POINT_COUNTS_I64) ? 1 : 0;
+    int nt = accv::tune_get("hm_nt", -1);
+    if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;
+    const dim3 grid((unsigned)tiles), block(64);
+    if (clear) {
+        if (nt >= 2)
+            hipLaunchKernelGGL((lane_raster_multi_kernel<true, 4>), grid, block, 0, stream, fp);
+        else
+            hipLaunchKernelGGL((lane_raster_multi_kernel<true, 0>), grid, block, 0, stream, fp);
+    } else {
+        if (nt >= 2)
+            hipLaunchKernelGGL((lane_raster_multi_kernel<false, 4>), grid, block, 0, stream, fp);
+        else
+            hipLaunchKernelGGL((lane_raster_multi_kernel<false, 0>), grid, block, 0, stream, fp);
+    }
+    note_dispatch("lane_raster_multi_kernel", 4, 8, clear, nt >= 2 ? 4 : 0, grid, block);
+    return accv::check_launch("draw_heatmap fused lane raster kernel");
 }
 
 int accv_heatmap_targets_from_boxes_f32(const float* centers_xy, const float* boxes_xyxy, long long num_objects,

@@ -27,6 +27,7 @@
 #include <limits>
 
 #include "accv_common.h"
+#include "polyline_arith.h"
 
 namespace {
 
@@ -157,7 +158,10 @@ __global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
             Acc acc2 = 0;
             for (int d = 0; d < p.D; ++d) {
                 const Acc diff = S::load(pts + (size_t)s * p.D + d) - S::load(pts + (size_t)(s + 1) * p.D + d);
-                acc2 += diff * diff;
+                if constexpr (TY == kPF32)
+                    acc2 = accv_poly::seg_length2_step(acc2, diff);   // (pinned: the fused lane raster repeats it, polyline_arith.h)
+                else
+                    acc2 += diff * diff;
             }
             sq[u] = acc2;
         }
@@ -221,7 +225,10 @@ __global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
         float bx = __builtin_nanf(""), by = bx;  // sample coordinates for the group box (D == 2, f32 instantiation)
         if (i < q_stop) {
             Acc d = S::load(dist + i);
-            if (p.relative) d *= total;
+            if (p.relative) {
+                if constexpr (TY == kPF32) d = accv_poly::scale_query(d, total);
+                else d *= total;
+            }
             T* res = out + (size_t)i * p.D;
             // last index whose accumulated distance is <= d (polyline_common.cuh:89-116)
             int idx;
@@ -245,8 +252,14 @@ __global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
                 const T* a = pts + (size_t)idx * p.D;
                 const T* c = a + p.D;
                 if (len >= eps) {
-                    const Acc w1 = (d - d0) / len, w0 = (d1 - d) / len;
-                    for (int k = 0; k < p.D; ++k) S::store(res + k, S::load(a + k) * w0 + S::load(c + k) * w1);
+                    if constexpr (TY == kPF32) {
+                        float w0, w1;
+                        accv_poly::lerp_weights(d, d0, d1, len, w0, w1);
+                        for (int k = 0; k < p.D; ++k) res[k] = accv_poly::lerp_coord(a[k], w0, c[k], w1);
+                    } else {
+                        const Acc w1 = (d - d0) / len, w0 = (d1 - d) / len;
+                        for (int k = 0; k < p.D; ++k) S::store(res + k, S::load(a + k) * w0 + S::load(c + k) * w1);
+                    }
                 } else {
                     for (int k = 0; k < p.D; ++k) S::copy(res + k, a + k);
                 }

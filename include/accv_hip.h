@@ -117,6 +117,27 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
                                     int radius, float diameter_to_sigma_factor, float k_scale, unsigned flags,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Lane raster of all scales in ONE launch: the tile waves work from the polylines themselves — polylines_xy
+ * f32[batch, lanes, points, 2] (source pixels), point_counts[batch * lanes] valid leading points per polyline (int32, or
+ * int64 with ACCV_HM_POINT_COUNTS_I64; null = all), lane_counts[batch] valid leading polylines per frame (int32, or int64
+ * with ACCV_HM_COUNTS_I64); every polyline is sampled at the num_samples arc-length fractions k / (num_samples - 1) (IEEE
+ * float division; one sample at fraction 0 for num_samples == 1).  Result: bit for bit what accv_polyline_sample_boxes
+ * (relative distances = those fractions, for every polyline) + accv_draw_points_multiscale_f32 write, without the sampler
+ * launch, the sample buffer and the workspace: a wave tests the SEGMENTS of the frame's polylines against its tile and
+ * repeats the sampler's arithmetic (polyline_common.cuh:58-163 semantics; csrc/polyline_arith.h) only for the stretch of
+ * samples on segments in reach.  That work is repeated per tile and scale, so the launch saved pays for SPARSE lane sets
+ * (one or two polylines per frame: 22.6-24.2 -> 17.8-18.6 us on config 3's maps) and the kernel takes only those:
+ * accv_draw_polylines_fused_applicable(...) == 1 for 1..64 points per polyline, lanes x P2 <= 64 with P2 = points rounded
+ * up to a power of two (>= 4), num_samples <= (points - 1) x P2 / 2, fine scales in the majority of the tiles; other shapes
+ * return ACCV_EINVAL — use the two-launch composition for them.  Same map constraints as the calls above. */
+#define ACCV_HM_POINT_COUNTS_I64 512u /* accv_draw_polylines_multiscale_f32: `point_counts` points to int64 */
+int accv_draw_polylines_fused_applicable(const int* heights, const int* widths, int num_scales, int batch, int lanes,
+                                         int points, int num_samples);
+int accv_draw_polylines_multiscale_f32(float* const* heatmaps, const int* heights, const int* widths, const float* strides,
+                                       int num_scales, int batch, const float* polylines_xy, int lanes, int points,
+                                       const void* point_counts, const void* lane_counts, int num_samples, int radius,
+                                       float diameter_to_sigma_factor, float k_scale, unsigned flags, void* stream);
+
 /* Target-prep front end: float centres [n,2] (x,y) and boxes [n,4] (x0,y0,x1,y1) in source pixels ->
  * int32 centres [n,2] = int(c / stride) and radii [n] = max(1, int(ceil(min edge distance / stride))) in ONE kernel.
  * Semantics of get_centers_and_radii (packages/draw_heatmap/tests/_test_helpers.py:20-28; the DALI path uses

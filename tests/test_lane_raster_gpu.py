@@ -206,9 +206,9 @@ def test_lane_splat_one_and_four_waves_per_tile_agree():
 
 
 def test_single_scale_call_takes_the_point_splat_and_equals_the_three_launch_formulation():
-    """draw_polylines_batched with a radius of a few pixels on an aligned map = the sampler + the point splat of
-    draw_polylines_multiscale with one scale (two launches, two-level cull); other radii / alignments = sampler -> integer
-    targets -> draw_heatmap_batched.  Bit-identical either way."""
+    """draw_polylines_batched with a radius of a few pixels on an aligned map = draw_polylines_multiscale with one scale (the
+    fused kernel, or the sampler + the point splat: two launches, two-level cull); other radii / alignments = sampler ->
+    integer targets -> draw_heatmap_batched.  Bit-identical either way."""
     from accvlab import _amd_native as nat
     from accvlab.draw_heatmap import draw_polylines_batched
     from accvlab.draw_heatmap.lanes import _draw_polylines_via_targets as via_targets
@@ -216,6 +216,7 @@ def test_single_scale_call_takes_the_point_splat_and_equals_the_three_launch_for
     dev = torch.device("cuda", 0)
     pts, npts, nlanes = _lanes(3, 5, 11, 1024.0, 512.0, seed=33, ragged=True)
     pts_d, npts_d, nlanes_d = torch.from_numpy(pts).to(dev), torch.from_numpy(npts).to(dev), torch.from_numpy(nlanes).to(dev)
+    # (five polylines of 11 points are more than the 64 point slots of the fused kernel, tests/test_lane_raster_fused_gpu.py)
     for stride, radius, width, kernel in ((2.0, 2, 512, "splat_points_multi_kernel"), (4.0, 0, 256, "splat_points_multi_kernel"),
                                           (4.0, 12, 256, "splat_kernel"), (4.0, 2, 254, "splat_kernel")):
         for clear in (True, False):
