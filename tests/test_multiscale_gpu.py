@@ -214,7 +214,11 @@ def test_scale_order_inside_the_launch_does_not_change_results(clear):
             assert "splat_multi_kernel" in nat.last_dispatch()
             lane_maps = [t.clone() for t in base]
             draw_polylines_multiscale(lane_maps, lanes, 64, 2, strides, clear=clear)
+            assert "lane_raster_multi_kernel" in nat.last_dispatch()      # 3 polylines x 9 points: the fused lane raster
+            more = [t.clone() for t in base]                              # ... and sampler + point splat (5 x 9 points)
+            draw_polylines_multiscale(more, torch.cat([lanes, lanes[:, :2] * 0.5], 1), 64, 2, strides, clear=clear)
             assert "splat_points_multi_kernel" in nat.last_dispatch()
+            lane_maps += more
         finally:
             ops._FORCED_FLAGS = 0
         results[label] = boxes + lane_maps
