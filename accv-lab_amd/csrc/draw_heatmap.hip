@@ -115,15 +115,17 @@ struct TileCtx {
     const int32_t* labels;
     const float2* centers_f;  // SRC == 1: float objects of this plane
     const float4* boxes_f;
+    float4 box0;             // SRC == 2 (SCALAR_COUNT): group box min(lane, n_groups - 1) of the plane, requested ahead of the count
     float stride;
     int radius;              // SRC == 2: the radius of every point
     int n, cls;              // cls < 0: no class filter
 };
 
+template <bool SCALAR_COUNT = false>
 __device__ __forceinline__ void plane_objects(const SplatParams& p, TileCtx& t);
 
 // tile coordinates from the launch geometry + the object range that feeds this plane; false = wave has no tile
-template <int TW, int TH, int WPG>
+template <int TW, int TH, int WPG, bool SCALAR_COUNT = false>
 __device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, TileCtx& t, long long linear_group)
 {
     int tx, ty;
@@ -153,11 +155,16 @@ __device__ __forceinline__ bool locate_tile(const SplatParams& p, int wave, Tile
     t.ty0 = ty * TH;
     t.tx1 = min(t.tx0 + TW, p.W);
     t.ty1 = min(t.ty0 + TH, p.H);
-    plane_objects(p, t);
+    plane_objects<SCALAR_COUNT>(p, t);
     return true;
 }
 
 // which objects feed plane t.plane: objects [obj_base, obj_base + n) of centers/radii(/labels)
+// SCALAR_COUNT: the plane's count is read through the scalar cache (constant address space: the array is not written by this
+// launch, and the scalar cache is invalidated between launches).  hipcc chooses that by itself while the parameters are read
+// straight from the kernel arguments, but falls back to a vector-memory load — ten times the latency, in front of everything a
+// short-lived tile wave does — once they are a preloaded copy (preload_params)
+template <bool SCALAR_COUNT>
 __device__ __forceinline__ void plane_objects(const SplatParams& p, TileCtx& t)
 {
     long long obj_base;
@@ -172,7 +179,18 @@ __device__ __forceinline__ void plane_objects(const SplatParams& p, TileCtx& t)
             s = t.plane / p.n_classes;
             t.cls = (int)(t.plane - s * p.n_classes);
         }
-        long long cnt = p.counts_i64 ? ((const long long*)p.counts)[s] : (long long)((const int*)p.counts)[s];
+        long long cnt;
+        if constexpr (SCALAR_COUNT) {
+            // the first round of group boxes does not depend on the count: requested first, so that both are in flight together
+            if (p.n_groups > 0)
+                t.box0 = reinterpret_cast<const float4*>(p.boxes_f)[t.plane * p.n_groups + min((int)(threadIdx.x & 63), p.n_groups - 1)];
+            using ConstI32 = const __attribute__((address_space(4))) int;
+            using ConstI64 = const __attribute__((address_space(4))) long long;
+            const uintptr_t base = reinterpret_cast<uintptr_t>(p.counts);
+            cnt = p.counts_i64 ? reinterpret_cast<ConstI64*>(base)[s] : (long long)reinterpret_cast<ConstI32*>(base)[s];
+        } else {
+            cnt = p.counts_i64 ? ((const long long*)p.counts)[s] : (long long)((const int*)p.counts)[s];
+        }
         t.n = (int)max(0ll, min(cnt, (long long)p.n_max));
         obj_base = s * p.n_max;
     }
@@ -444,12 +462,62 @@ __global__ __launch_bounds__(WPG * 64) void splat_kernel(const SplatParams p)
 // scale; a workgroup finds its scale from the tile prefix (wave-uniform), and the candidates are the FLOAT centres and
 // boxes in source pixels, converted to that scale's integer centre / radius inside the cull (same arithmetic as
 // targets_from_boxes_kernel), so the front end needs no launch and no intermediate tensors at all.
+// Prologue of the multi-scale kernels.  Their tiles are short-lived waves (most of a lane raster's tiles store zeros and leave),
+// and what such a wave did first was a CHAIN of dependent scalar loads: number of scales -> prefix entry after prefix entry ->
+// one field of the scale's parameters, a branch, the next field ... (~20 load / wait pairs in the ISA of round 3's point splat).
+// Here the scale comes from the whole prefix at once, without a branch (entries past the last scale hold the total: never
+// matched), and the scale's parameters are copied in one batch of loads, held there by empty asm statements.
+__device__ __forceinline__ int scale_of_group(const MultiParams& mp, long long group, long long& first)
+{
+    int s = 0;
+    first = 0;   // tile_begin[0]
+#pragma unroll
+    for (int i = 1; i < kMaxScales; ++i) {
+        const long long begin = mp.tile_begin[i];
+        if (group >= begin) {
+            s = i;
+            first = begin;
+        }
+    }
+    return s;
+}
+template <typename T>
+__device__ __forceinline__ void pin_scalar(T& v)
+{
+    asm volatile("" : "+s"(v));
+}
+__device__ __forceinline__ SplatParams preload_params(const SplatParams& src)
+{
+    SplatParams p = src;
+    // (the pointers are left alone: behind an asm statement hipcc no longer knows them to be global memory and turns every load
+    // through them — the frame's count, a scalar load before — into a flat VMEM load)
+    asm volatile("" ::"s"(p.hm), "s"(p.counts), "s"(p.centers_f), "s"(p.boxes_f));   // (requested with the rest, value untouched)
+    pin_scalar(p.H);
+    pin_scalar(p.W);
+    pin_scalar(p.n_max);
+    pin_scalar(p.n_classes);
+    pin_scalar(p.tiles_x);
+    pin_scalar(p.tiles_y);
+    pin_scalar(p.n_tiles);
+    pin_scalar(p.factor);
+    pin_scalar(p.k);
+    pin_scalar(p.counts_i64);
+    pin_scalar(p.grid3d);
+    pin_scalar(p.dense_area);
+    pin_scalar(p.stride);
+    pin_scalar(p.radius);
+    pin_scalar(p.n_groups);
+    return p;
+}
+
 template <bool CLEAR, int SM>
 __global__ __launch_bounds__(64) void splat_multi_kernel(const MultiParams mp)
 {
-    int s = 0;
-    while (s + 1 < mp.n_scales && (long long)blockIdx.x >= mp.tile_begin[s + 1]) ++s;
-    splat_body<4, 8, CLEAR, SM, 1, 1>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s]);
+    long long first;
+    const int s = scale_of_group(mp, blockIdx.x, first);
+    // (the scale's parameters are NOT requested up front here, neither as copies (preload_params) nor as asm inputs: either way
+    // the register-bound tile body goes from 79 to 85-124 VGPRs and loses one or two waves per SIMD)
+    splat_body<4, 8, CLEAR, SM, 1, 1>(mp.scale[s], (long long)blockIdx.x - first);
 }
 
 // ---------------------------------------------------------------- small splats (lane rasters, point-like targets)
@@ -557,12 +625,16 @@ struct GroupBox {
     float x0, y0, x1, y1;
     bool valid;
 };
+template <bool FIRST = false>   // FIRST: g = lane, the box plane_objects<true> requested (t.box0)
 __device__ __forceinline__ GroupBox load_group_box(const SplatParams& p, const TileCtx& t, int g)
 {
     // the load is UNCONDITIONAL (index clamped; callers run only with n_groups >= 1): its address does not depend on the
     // plane's sample count, so it is in flight together with the count's load instead of behind it — one dependent round
     // trip less in front of every tile's first store
-    const float4 v = t.boxes_f[min(g, p.n_groups - 1)];
+    float4 v = FIRST ? t.box0 : t.boxes_f[min(g, p.n_groups - 1)];
+    // (all four components at once: left alone, hipcc splits the load and sinks three of the pieces into the short-circuit
+    // evaluation of group_reaches() — up to three dependent round trips to memory where one does)
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
     return GroupBox{v.x, v.y, v.z, v.w, g < p.n_groups && g * kCand < t.n && v.x <= v.z};
 }
 // can a sample of the group reach pixel columns [cx0, cx1) x rows [cy0, cy1) of this scale?  CONSERVATIVE and division-free
@@ -640,7 +712,7 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
     const int lane = threadIdx.x & 63;
     const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
     TileCtx t;
-    if (!locate_tile<TW, TH, 1>(p, 0, t, linear_group)) return;  // uniform over the workgroup
+    if (!locate_tile<TW, TH, 1, SRC == 2>(p, 0, t, linear_group)) return;  // uniform over the workgroup
     const int sub = lane >> 5, col0 = t.tx0 + (lane & 31) * 4;
     const int row0 = wave * (TH / NW) + sub * RPW;               // first of this half-wave's rows
     float* plane_ptr = p.hm + (size_t)t.plane * (size_t)p.H * (size_t)p.W;
@@ -683,7 +755,7 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         const int rows_hint = 2 * min(rc, 64) + 1;   // every sample has the same radius: no clipped box is taller
         const ReachBounds rb = reach_bounds(t, rc, t.tx0, t.tx1, t.ty0, t.ty1);
         for (int g0 = 0; g0 < p.n_groups; g0 += kCand) {
-            unsigned long long mg = __ballot(group_reaches(load_group_box(p, t, g0 + lane), rb));
+            unsigned long long mg = __ballot(group_reaches(g0 == 0 ? load_group_box<true>(p, t, lane) : load_group_box(p, t, g0 + lane), rb));
             if (mg == 0) continue;
             if constexpr (NW > 1) {  // every wave found the same groups; this one walks the (k * NW + wave)-th of them
                 unsigned long long mine = 0;
@@ -805,9 +877,10 @@ __global__ __launch_bounds__(NW * 64) void splat_points_multi_kernel(const Multi
 {
     __shared__ Hit s_hit[NW][kCand];
     __shared__ __attribute__((aligned(16))) float s_tile[TH][kSmallLdsW];
-    int s = 0;
-    while (s + 1 < mp.n_scales && (long long)blockIdx.x >= mp.tile_begin[s + 1]) ++s;
-    small_body<CLEAR, SM, 2, NW, TH>(mp.scale[s], (long long)blockIdx.x - mp.tile_begin[s], s_hit, s_tile);
+    long long first;
+    const int s = scale_of_group(mp, blockIdx.x, first);
+    const SplatParams p = preload_params(mp.scale[s]);
+    small_body<CLEAR, SM, 2, NW, TH>(p, (long long)blockIdx.x - first, s_hit, s_tile);
 }
 
 // ---------------------------------------------------------------- fused lane raster: polylines -> maps, ONE launch
@@ -886,7 +959,7 @@ __device__ __forceinline__ void lane_body(const SplatParams& p, const LaneParams
     constexpr int TW = kSmallTW, TH = kSmallTH, RPW = TH / 2;
     const int lane = threadIdx.x & 63;
     TileCtx t;
-    if (!locate_tile<TW, TH, 1>(p, 0, t, linear_group)) return;   // t.n = valid polylines of this frame (<= L)
+    if (!locate_tile<TW, TH, 1, true>(p, 0, t, linear_group)) return;   // t.n = valid polylines of this frame (<= L)
     const int sub = lane >> 5, col0 = t.tx0 + (lane & 31) * 4, row0 = sub * RPW;
     float* plane_ptr = p.hm + (size_t)t.plane * (size_t)p.H * (size_t)p.W;
 
@@ -1107,9 +1180,10 @@ __global__ __launch_bounds__(64) void lane_raster_multi_kernel(const FusedLanePa
 {
     __shared__ Hit s_hit[kCand];
     __shared__ __attribute__((aligned(16))) float s_tile[kSmallTH][kSmallLdsW];
-    int s = 0;
-    while (s + 1 < fp.mp.n_scales && (long long)blockIdx.x >= fp.mp.tile_begin[s + 1]) ++s;
-    lane_body<CLEAR, SM>(fp.mp.scale[s], fp.lp, (long long)blockIdx.x - fp.mp.tile_begin[s], s_hit, s_tile);
+    long long first;
+    const int s = scale_of_group(fp.mp, blockIdx.x, first);
+    const SplatParams p = preload_params(fp.mp.scale[s]);
+    lane_body<CLEAR, SM>(p, fp.lp, (long long)blockIdx.x - first, s_hit, s_tile);
 }
 
 // bounding box (xmin, ymin, xmax, ymax) of every 64 consecutive points of points[b, :, :] (NaN points ignored; a group
@@ -1479,6 +1553,12 @@ inline void coarse_scales_first(MultiParams& mp)
     }
     mp.tile_begin[mp.n_scales] = tiles;
 }
+// entries of the tile prefix past the last scale = the total, so that the kernels find a workgroup's scale with plain
+// comparisons (scale_of_group)
+inline void seal_tile_prefix(MultiParams& mp)
+{
+    for (int i = mp.n_scales + 1; i <= kMaxScales; ++i) mp.tile_begin[i] = mp.tile_begin[mp.n_scales];
+}
 
 }  // namespace
 
@@ -1654,6 +1734,7 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
     if (used == 0 || tiles == 0) return ACCV_OK;
     if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: %lld tiles exceed the grid limit", tiles);
     if (!(flags & ACCV_HM_CALLER_SCALE_ORDER)) coarse_scales_first(mp);
+    seal_tile_prefix(mp);
     int nt = accv::tune_get("hm_nt", -1);
     if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;   // same store policy as the single-scale path
     const dim3 grid((unsigned)tiles), block(64);
@@ -1743,6 +1824,7 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
     if (used == 0 || tiles == 0) return ACCV_OK;
     if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: %lld tiles exceed the grid limit", tiles);
     if (!(flags & ACCV_HM_CALLER_SCALE_ORDER)) coarse_scales_first(mp);
+    seal_tile_prefix(mp);
     const long long total_groups = (long long)batch * n_groups;
     if (total_groups > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_points_multiscale: too many point groups");
     if (total_groups > 0 && !(flags & ACCV_HM_GROUP_BOXES_GIVEN))
@@ -1774,6 +1856,7 @@ int accv_draw_points_multiscale_f32(float* const* heatmaps, const int* heights, 
             t8 += p.n_tiles;
         }
         mp.tile_begin[used] = t8;
+        seal_tile_prefix(mp);
         const dim3 grid8((unsigned)t8);
         if (clear)
             hipLaunchKernelGGL((splat_points_multi_kernel<true, 0, 1, 8>), grid8, dim3(64), 0, stream, mp);
@@ -1911,6 +1994,7 @@ int accv_draw_polylines_multiscale_f32(float* const* heatmaps, const int* height
     if (used == 0 || tiles == 0) return ACCV_OK;
     if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_polylines_multiscale: %lld tiles exceed the grid limit", tiles);
     if (!(flags & ACCV_HM_CALLER_SCALE_ORDER)) coarse_scales_first(mp);
+    seal_tile_prefix(mp);
     fp.lp.points = reinterpret_cast<const float2*>(polylines_xy);
     fp.lp.point_counts = point_counts;
     fp.lp.L = lanes;
