@@ -857,7 +857,8 @@ __global__ __launch_bounds__(64) void splat_small_kernel(const SplatParams p)
 {
     __shared__ Hit s_hit[1][kCand];
     __shared__ __attribute__((aligned(16))) float s_tile[kSmallTH][kSmallLdsW];
-    small_body<CLEAR, SM, 0>(p, blockIdx.x, s_hit, s_tile);
+    small_body<CLEAR, SM, 0>(p, blockIdx.x, s_hit, s_tile);   // (preload_params: +-1 % here — the one-level cull over 10^3 candidates
+                                                              // is not bound by its prologue, profiles/r03_prologue_preload_elsewhere.log)
 }
 
 // lane rasters of all scales in one launch: float sample points, two-level cull (SRC = 2), scale from the tile prefix.
