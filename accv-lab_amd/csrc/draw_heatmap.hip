@@ -655,14 +655,35 @@ __device__ __forceinline__ bool group_reaches(const GroupBox& b, const ReachBoun
     return b.valid && b.x1 >= rb.xlo && b.x0 < rb.xhi && b.y1 >= rb.ylo && b.y0 < rb.yhi;
 }
 
-// candidates of sample group `g` (one per lane); consecutive samples that land on the same pixel are one and the same splat
-// (coarse scales see several samples per pixel): the first of a run is kept, results are unchanged
-__device__ __forceinline__ Cand load_group_candidates(const TileCtx& t, int sub_base, int lane)
+// data-parallel-primitive moves (gfx9 DPP controls); lanes without a source lane keep `old`
+constexpr int kDppQuad0 = 0x00, kDppQuad1 = 0x55, kDppQuad2 = 0xAA, kDppQuad3 = 0xFF;   // broadcast lane 0..3 of every quad
+constexpr int kDppRowShr = 0x110;                                                      // + n: lane i <- lane i - n inside rows of 16
+constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;                              // lane i <- lane i + 1 / i - 1, whole wave
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float old, float src)
 {
-    Cand c = cull_load<2>(t, sub_base, lane);
-    const int nx = __shfl_up(c.x, 1), ny = __shfl_up(c.y, 1), nr = __shfl_up(c.r, 1);
-    if (lane > 0 && nx == c.x && ny == c.y && nr == c.r) c.r = -1;
-    return c;
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, 0xf, false);
+}
+// candidates of sample group `g` (one per lane), in two steps so that the requests of several groups are in flight together
+// (fetch + use in one function made every group its own round trip to memory: the use waits for the data): the raw sample ...
+__device__ __forceinline__ float2 request_group_samples(const TileCtx& t, int sub_base, int lane)
+{
+    return t.centers_f[min(sub_base + lane, t.n - 1)];  // n >= 1 inside the candidate loop
+}
+// ... and its target at this scale, exactly cull_load<2>; consecutive samples that land on the same pixel are one and the same
+// splat (coarse scales see several samples per pixel): the first of a run is kept, results are unchanged
+__device__ __forceinline__ Cand group_candidates(const TileCtx& t, const float2 c, int lane)
+{
+    Cand out{(int)__fdiv_rn(c.x, t.stride), (int)__fdiv_rn(c.y, t.stride), t.radius, 0};
+    if ((c.x != c.x) || (c.y != c.y)) out = Cand{0, 0, -1, 0};
+    const int nx = dpp_i<kDppWaveShr1>(0, out.x), ny = dpp_i<kDppWaveShr1>(0, out.y), nr = dpp_i<kDppWaveShr1>(-2, out.r);
+    if (lane > 0 && nx == out.x && ny == out.y && nr == out.r) out.r = -1;
+    return out;
 }
 
 template <int SM>
@@ -683,22 +704,43 @@ __device__ __forceinline__ void write_back_rows(const SplatParams& p, const Tile
                                                 int lane, int col0)
 {
     const float init = CLEAR ? 0.0f : -__builtin_inff();
-    constexpr int kUnroll = RPW > 2 ? 2 : RPW;
-#pragma unroll kUnroll
-    for (int i = 0; i < RPW; ++i) {
-        const int row = t.ty0 + row0 + i;
-        if (row >= p.H) break;
-        vfloat4 out = *reinterpret_cast<const vfloat4*>(&tile[row0 + i][(lane & 31) * 4]);
-        if constexpr (!CLEAR) {
-            if (out.x == init && out.y == init && out.z == init && out.w == init) continue;
-            const vfloat4 old = *reinterpret_cast<const vfloat4*>(plane_ptr + (size_t)row * p.W + col0);
+    // the rows are read from LDS in batches of up to four (all reads of a batch in flight together — one row at a time was a chain
+    // of RPW LDS round trips at the end of every touched tile), in place the old segments of a batch are requested together too
+    constexpr int kBatch = RPW > 4 ? 4 : RPW;
+    static_assert(RPW % kBatch == 0, "rows per half-wave come in whole batches");
+#pragma unroll
+    for (int i0 = 0; i0 < RPW; i0 += kBatch) {
+        vfloat4 out[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) out[i] = *reinterpret_cast<const vfloat4*>(&tile[row0 + i0 + i][(lane & 31) * 4]);
+        if constexpr (CLEAR) {
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) {
+                const int row = t.ty0 + row0 + i0 + i;
+                if (row < p.H) store_segment<SM>(p, plane_ptr, row, col0, out[i]);
+            }
+        } else {
+            bool dirty[kBatch];
+            vfloat4 old[kBatch];
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) {
+                const int row = t.ty0 + row0 + i0 + i;
+                dirty[i] = row < p.H && !(out[i].x == init && out[i].y == init && out[i].z == init && out[i].w == init);
+                old[i] = vfloat4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (dirty[i]) old[i] = *reinterpret_cast<const vfloat4*>(plane_ptr + (size_t)row * p.W + col0);
+            }
             const float nanv = __builtin_nanf("");
-            out.x = max_skip_nan(old.x, out.x == init ? nanv : out.x);
-            out.y = max_skip_nan(old.y, out.y == init ? nanv : out.y);
-            out.z = max_skip_nan(old.z, out.z == init ? nanv : out.z);
-            out.w = max_skip_nan(old.w, out.w == init ? nanv : out.w);
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) {
+                if (!dirty[i]) continue;
+                vfloat4 o = out[i];
+                o.x = max_skip_nan(old[i].x, o.x == init ? nanv : o.x);
+                o.y = max_skip_nan(old[i].y, o.y == init ? nanv : o.y);
+                o.z = max_skip_nan(old[i].z, o.z == init ? nanv : o.z);
+                o.w = max_skip_nan(old[i].w, o.w == init ? nanv : o.w);
+                store_segment<SM>(p, plane_ptr, t.ty0 + row0 + i0 + i, col0, o);
+            }
         }
-        store_segment<SM>(p, plane_ptr, row, col0, out);
     }
 }
 
@@ -767,20 +809,25 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
             do {  // wave-uniform; the candidates of up to four groups are fetched together (one round trip)
                 constexpr int kFetch = 4;
                 int sub_base[kFetch];
+                float2 raw[kFetch];
                 Cand cand[kFetch];
 #pragma unroll
                 for (int u = 0; u < kFetch; ++u) {
                     sub_base[u] = -1;
+                    raw[u] = float2{0.0f, 0.0f};
                     if (mg) {
                         sub_base[u] = (g0 + __builtin_ctzll(mg)) * kCand;
                         mg &= mg - 1;
-                        cand[u] = load_group_candidates(t, sub_base[u], lane);
+                        raw[u] = request_group_samples(t, sub_base[u], lane);
                     }
                 }
                 // NW > 1: the tile is set up (LDS writes + a barrier, uniform over the workgroup: every wave saw the same
                 // groups and comes through here even when none of them is its own) BEHIND the candidate requests, so that
                 // the barrier overlaps their flight
                 if constexpr (NW > 1) prepare_tile();
+#pragma unroll
+                for (int u = 0; u < kFetch; ++u)
+                    if (sub_base[u] >= 0) cand[u] = group_candidates(t, raw[u], lane);
                 // Round 3: the hits of the (up to four) fetched groups go into ONE list and are walked together when they fit
                 // it — a tile of a coarse scale is crossed by several lanes, each contributing a handful of samples per
                 // group, and one compaction + one walk replaces four dependent ballot / LDS / fence / walk rounds
@@ -926,20 +973,6 @@ struct FusedLaneParams {
     LaneParams lp;
 };
 
-// data-parallel-primitive moves (gfx9 DPP controls); lanes without a source lane keep `old`
-constexpr int kDppQuad0 = 0x00, kDppQuad1 = 0x55, kDppQuad2 = 0xAA, kDppQuad3 = 0xFF;   // broadcast lane 0..3 of every quad
-constexpr int kDppRowShr = 0x110;                                                      // + n: lane i <- lane i - n inside rows of 16
-constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;                              // lane i <- lane i + 1 / i - 1, whole wave
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float old, float src)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int old, int src)
-{
-    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, 0xf, false);
-}
 __device__ __forceinline__ float lane_read(float v, int src_lane)
 {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
