@@ -52,6 +52,8 @@ SIGNATURES = {
     "accv_draw_heatmap_batched_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _u, _vp]),
     "accv_fill_f32": (_i, [_vp, _sz, _f, _vp]),
     "accv_draw_heatmap_multiscale_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _f, _f, _u, _vp]),
+    "accv_draw_heatmap_multiscale_sample_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _f, _f, _u,
+                                                      _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "accv_draw_points_workspace_bytes": (_sz, [_i, _i]),
     "accv_draw_points_multiscale_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _f, _f, _u, _vp, _sz, _vp]),
     "accv_draw_polylines_fused_applicable": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),

@@ -204,10 +204,88 @@ def _draw_polylines_fused(heatmaps, hs, ws_, strides, polylines, num_samples, ra
     _nat.check(status, "draw_polylines_multiscale")
 
 
+def _fused_applies(lib, hs, ws_, k, polylines, num_samples) -> bool:
+    b, l = polylines.shape[:2] if polylines.dim() == 4 else (0, 0)
+    return bool(FUSED_SAMPLER and b * l > 0 and polylines.dtype == torch.float32 and polylines.dim() == 4 and
+                lib.accv_draw_polylines_fused_applicable(hs, ws_, k, b, l, polylines.size(2), num_samples))
+
+
+class _SamplerJob:
+    """The polyline sampler as a rider of the box-map launch (draw_targets_multiscale): where to read the polylines and where to
+    write samples and group boxes.  ``run_separately`` is the fall-back when the box maps do not take the one-launch kernel."""
+
+    def __init__(self, polylines, num_points, num_samples, work):
+        b, l, p, _ = polylines.shape
+        self.polylines, self.num_points_arg, self.num_samples, self.work = polylines, num_points, num_samples, work
+        self.points = polylines.contiguous()
+        self.num_polylines, self.num_points = b * l, p
+        self.counts = None
+        self.flags = 0
+        if num_points is not None:
+            if not (num_points.shape == (b, l) and num_points.device == polylines.device):
+                raise RuntimeError("num_points must be of shape [batch, lanes] on the polylines' device")
+            _poly._check_sizes(num_points.reshape(-1), p, "num_points")
+            self.counts = num_points.contiguous().view(b * l)
+            if self.counts.dtype not in (torch.int32, torch.int64):
+                self.counts = self.counts.to(torch.int64)
+            if self.counts.dtype == torch.int64:
+                self.flags = _nat.HM_POINT_COUNTS_I64
+        self.samples = torch.empty((b, l * num_samples, 2), dtype=torch.float32, device=polylines.device)
+
+    def run_separately(self):
+        self.samples = sample_lanes(self.polylines, self.num_samples, num_points=self.num_points_arg,
+                                    group_boxes_ptr=self.work.data_ptr())
+
+
+def draw_targets_multiscale(heatmaps, centers, bboxes, out_size_factors, lane_heatmaps, polylines: torch.Tensor, num_samples: int,
+                            radius: int, lane_out_size_factors=None, diameter_to_sigma_factor: float = 6.0, k_scale: float = 1.0, *,
+                            num_points: Optional[torch.Tensor] = None, num_lanes: Optional[torch.Tensor] = None,
+                            clear: bool = False) -> None:
+    """(extension) Box maps and lane maps of one training step (BASELINE config 3).  Equivalent to::
+
+        draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diameter_to_sigma_factor, k_scale, clear=clear)
+        draw_polylines_multiscale(lane_heatmaps, polylines, num_samples, radius, lane_out_size_factors or out_size_factors,
+                                  diameter_to_sigma_factor, k_scale, num_points=num_points, num_lanes=num_lanes, clear=clear)
+
+    bit for bit, in TWO launches instead of three: the polyline sampler's workgroups ride in the box-map launch, which does not
+    depend on them, and the point splat follows.  Needs polylines of at most 64 points and a multiple of 64 samples; other
+    shapes (and lane sets the one-launch lane raster takes anyway) run the two calls above."""
+    heatmaps, lane_heatmaps = list(heatmaps), list(lane_heatmaps)
+    lane_strides = [float(f) for f in (out_size_factors if lane_out_size_factors is None else lane_out_size_factors)]
+    ok = isinstance(polylines, torch.Tensor) and polylines.is_cuda and polylines.dim() == 4 and polylines.size(3) == 2 and \
+        polylines.dtype == torch.float32 and polylines.size(0) * polylines.size(1) > 0 and polylines.size(2) <= 64 and \
+        num_samples % 64 == 0 and 64 <= num_samples <= (1 << 20) and 1 <= len(lane_heatmaps) <= 4 and radius >= 0 and \
+        len(lane_heatmaps) == len(lane_strides)
+    for hm in lane_heatmaps:
+        ok = ok and isinstance(hm, torch.Tensor) and hm.is_cuda and hm.dim() == 3 and hm.is_contiguous() and \
+            hm.dtype == torch.float32 and hm.size(0) == polylines.size(0) and hm.device == polylines.device and \
+            hm.size(2) % 4 == 0 and hm.data_ptr() % 16 == 0 and hm.size(1) * hm.size(2) * 4 < (1 << 31)
+    if ok:
+        k = len(lane_heatmaps)
+        hs = (ctypes.c_int * k)(*[hm.size(1) for hm in lane_heatmaps])
+        ws_ = (ctypes.c_int * k)(*[hm.size(2) for hm in lane_heatmaps])
+        ok = not _fused_applies(_nat.lib(), hs, ws_, k, polylines, num_samples)
+    if not ok:
+        _ops.draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diameter_to_sigma_factor, k_scale, clear=clear)
+        draw_polylines_multiscale(lane_heatmaps, polylines, num_samples, radius, lane_strides, diameter_to_sigma_factor, k_scale,
+                                  num_points=num_points, num_lanes=num_lanes, clear=clear)
+        return
+    b, l = polylines.shape[:2]
+    dev = polylines.device
+    with _nat.device_guard(dev):
+        nbytes = _nat.lib().accv_draw_points_workspace_bytes(b, l * num_samples)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    job = _SamplerJob(polylines, num_points, num_samples, work)
+    _ops.draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diameter_to_sigma_factor, k_scale, clear=clear,
+                                 _sampler_job=job)
+    draw_polylines_multiscale(lane_heatmaps, polylines, num_samples, radius, lane_strides, diameter_to_sigma_factor, k_scale,
+                              num_points=num_points, num_lanes=num_lanes, clear=clear, _presampled=(job.samples, work))
+
+
 def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: int, radius: int, out_size_factors,
                               diameter_to_sigma_factor: float = 6.0, k_scale: float = 1.0, *,
                               num_points: Optional[torch.Tensor] = None, num_lanes: Optional[torch.Tensor] = None,
-                              clear: bool = False) -> None:
+                              clear: bool = False, _presampled=None) -> None:
     """Lane raster at several strides: equivalent to ``draw_polylines_batched(heatmaps[s], polylines, num_samples, radius,
     out_size_factors[s], ...)`` for every scale, in THREE launches altogether (sampler, group boxes, one splat over the
     tiles of all scales) instead of three per scale.  The splat culls in two levels — 64 consecutive samples share a
@@ -236,19 +314,23 @@ def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: in
     k = len(heatmaps)
     hs = (ctypes.c_int * k)(*[hm.size(1) for hm in heatmaps])
     ws_ = (ctypes.c_int * k)(*[hm.size(2) for hm in heatmaps])
-    if FUSED_SAMPLER and b * l > 0 and polylines.dtype == torch.float32 and polylines.dim() == 4 and \
-            lib.accv_draw_polylines_fused_applicable(hs, ws_, k, b, l, polylines.size(2), num_samples):
+    if _presampled is None and _fused_applies(lib, hs, ws_, k, polylines, num_samples):
         # ONE launch: the tile waves sample the polylines themselves (no sampler launch, no sample buffer)
         _draw_polylines_fused(heatmaps, hs, ws_, strides, polylines, num_samples, radius, diameter_to_sigma_factor, k_scale,
                               num_points, num_lanes, clear)
         return
-    with _nat.device_guard(dev):
-        nbytes = lib.accv_draw_points_workspace_bytes(b, n)
-        work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    # the sampler writes the group boxes itself when the groups of 64 do not straddle lanes (one launch less)
-    boxes_by_sampler = num_samples % 64 == 0 and b * l > 0
-    samples = sample_lanes(polylines, num_samples, num_points=num_points,
-                           group_boxes_ptr=work.data_ptr() if boxes_by_sampler else 0)
+    if _presampled is not None:   # (draw_targets_multiscale) samples and group boxes were written by the box-map launch
+        samples, work = _presampled
+        nbytes = work.numel()
+        boxes_by_sampler = True
+    else:
+        with _nat.device_guard(dev):
+            nbytes = lib.accv_draw_points_workspace_bytes(b, n)
+            work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        # the sampler writes the group boxes itself when the groups of 64 do not straddle lanes (one launch less)
+        boxes_by_sampler = num_samples % 64 == 0 and b * l > 0
+        samples = sample_lanes(polylines, num_samples, num_points=num_points,
+                               group_boxes_ptr=work.data_ptr() if boxes_by_sampler else 0)
     if num_lanes is None:
         sizes = _cached(("full", b, n, dev), lambda: torch.full((b,), n, dtype=torch.int32, device=dev))
     else:

@@ -327,7 +327,7 @@ def get_centers_and_radii(centers, bboxes, out_size_factor: float):
 
 
 def draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diameter_to_sigma_factor: float = 6.0,
-                            k_scale: float = 1.0, *, clear: bool = False) -> None:
+                            k_scale: float = 1.0, *, clear: bool = False, _sampler_job=None) -> None:
     """(extension) Rasterise one batch of objects at several strides.  Equivalent to, for every scale ``s``::
 
         c, r = get_centers_and_radii(centers, bboxes, out_size_factors[s])
@@ -375,6 +375,8 @@ def draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diamete
         for hm, f in zip(heatmaps, strides):
             ci, ri = get_centers_and_radii(centers, bboxes, f)
             draw_heatmap_batched(hm, ci, ri, diameter_to_sigma_factor, k_scale, clear=clear)
+        if _sampler_job is not None:
+            _sampler_job.run_separately()
         return
     n = len(heatmaps)
     ptrs = (ctypes.c_void_p * n)(*[hm.data_ptr() for hm in heatmaps])
@@ -384,7 +386,15 @@ def draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diamete
     flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0) | _FORCED_FLAGS
     dev = heatmaps[0].device
     with _nat.device_guard(dev):
-        status = _nat.lib().accv_draw_heatmap_multiscale_f32(
-            ptrs, hs, ws, st, n, batch, c_t.data_ptr(), b_t.data_ptr(), counts.data_ptr(), n_max,
-            float(diameter_to_sigma_factor), float(k_scale), flags, _nat.stream_ptr(dev))
+        if _sampler_job is None:
+            status = _nat.lib().accv_draw_heatmap_multiscale_f32(
+                ptrs, hs, ws, st, n, batch, c_t.data_ptr(), b_t.data_ptr(), counts.data_ptr(), n_max,
+                float(diameter_to_sigma_factor), float(k_scale), flags, _nat.stream_ptr(dev))
+        else:   # (draw_targets_multiscale) the polyline sampler rides in the same launch
+            j = _sampler_job
+            status = _nat.lib().accv_draw_heatmap_multiscale_sample_f32(
+                ptrs, hs, ws, st, n, batch, c_t.data_ptr(), b_t.data_ptr(), counts.data_ptr(), n_max,
+                float(diameter_to_sigma_factor), float(k_scale), flags | j.flags, j.points.data_ptr(), j.num_polylines, j.num_points,
+                j.counts.data_ptr() if j.counts is not None else None, j.num_samples, j.samples.data_ptr(), j.work.data_ptr(),
+                _nat.stream_ptr(dev))
     _nat.check(status, "draw_heatmap_multiscale")

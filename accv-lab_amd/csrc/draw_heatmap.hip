@@ -986,6 +986,79 @@ __device__ __forceinline__ T pick(int r, const T (&a)[N])   // a[r] for a wave-u
     return v;
 }
 
+// ---- the f32 polyline sampler at wave level: the polylines sit one per block of P2 lanes (P2 a power of two, 4..64), point j of
+// a block's polyline in the block's lane j.  Bit for bit polyline_kernel<f32, 256> for polylines of at most 64 points (see
+// the notes above lane_body); every lane of the wave must be active in both functions (lane exchanges).
+// accumulated distance of the lane's point (valid for j < n) and the polyline's length
+__device__ __forceinline__ float polyline_accumulate(float px, float py, float next_x, float next_y, int n, int j, int lb, int P2,
+                                                     float& total)
+{
+    float len = 0.0f;   // polyline_kernel: diff = point[s] - point[s + 1], acc = fma(diff, diff, acc) per coordinate, sqrt
+    if (j + 1 < n) len = sqrtf(accv_poly::seg_length2_step(accv_poly::seg_length2_step(0.0f, px - next_x), py - next_y));
+    const float v0 = dpp_f<kDppQuad0>(len, len), v1 = dpp_f<kDppQuad1>(len, len), v2 = dpp_f<kDppQuad2>(len, len),
+                v3 = dpp_f<kDppQuad3>(len, len);
+    const float chunk = ((v0 + v1) + v2) + v3;
+    const float total4 = lane_read(chunk, lb + ((j << 2) & (P2 - 1)));   // (every lane takes part in the exchange)
+    const float own = j < (P2 >> 2) ? total4 : 0.0f;
+    float incl = own;   // lanes j < P2 / 4 <= 16 of the block hold its totals; they sit in one row of 16
+    {
+        float up = dpp_f<kDppRowShr + 1>(0.0f, incl);
+        if (j >= 1) incl += up;
+        up = dpp_f<kDppRowShr + 2>(0.0f, incl);
+        if (j >= 2) incl += up;
+        up = dpp_f<kDppRowShr + 4>(0.0f, incl);
+        if (j >= 4) incl += up;
+        up = dpp_f<kDppRowShr + 8>(0.0f, incl);
+        if (j >= 8) incl += up;
+    }
+    const float excl = incl - own;
+    float base = lane_read(excl, lb + (j >> 2));
+    const int u4 = j & 3;
+    if (u4 >= 1) base += v0;
+    if (u4 >= 2) base += v1;
+    if (u4 >= 3) base += v2;
+    const float acc_next = base != 0.0f ? len + base : len;   // accum[j + 1]
+    const float up1 = dpp_f<kDppWaveShr1>(0.0f, acc_next);
+    const float acc = j == 0 ? 0.0f : up1;                    // accum[j]
+    total = lane_read(acc, lb + max(n - 1, 0));
+    return acc;
+}
+// the point at distance d along the lane's polyline (acc / px / py: what polyline_accumulate saw and returned; `act` = this lane
+// wants a result — idle lanes still run along)
+__device__ __forceinline__ void polyline_sample_at(float d, float acc, float px, float py, float total, int n, int lb, bool act,
+                                                   float& sx, float& sy)
+{
+    // last point whose accumulated distance is <= d (polyline_kernel; all lanes stay in the loop for the exchanges)
+    int mn = 0, mx = max(n - 1, 0);
+    while (__ballot(act && mx - mn > 1)) {
+        const int c = (mx + mn) >> 1;
+        const float v = lane_read(acc, lb + c);
+        if (mx - mn > 1) {
+            if (v < d) mn = c;
+            else if (v > d) mx = c;
+            else mn = mx = c;
+        }
+    }
+    int idx = mn;
+    if (0.0f > d) idx = -1;
+    else if (total < d) idx = n - 1;
+    const int ia = min(max(idx, 0), max(n - 1, 0)), ic = min(ia + 1, max(n - 1, 0));
+    const float d0 = lane_read(acc, lb + ia), d1 = lane_read(acc, lb + ic);
+    const float pax = lane_read(px, lb + ia), pay = lane_read(py, lb + ia);
+    const float pcx = lane_read(px, lb + ic), pcy = lane_read(py, lb + ic);
+    sx = pax;   // before the first / beyond the last point, or a segment shorter than epsilon
+    sy = pay;
+    if (idx >= 0 && idx < n - 1) {
+        const float seg_len = d1 - d0;
+        if (seg_len >= 1.1920928955078125e-07f) {
+            float w0, w1;
+            accv_poly::lerp_weights(d, d0, d1, seg_len, w0, w1);
+            sx = accv_poly::lerp_coord(pax, w0, pcx, w1);
+            sy = accv_poly::lerp_coord(pay, w0, pcy, w1);
+        }
+    }
+}
+
 template <bool CLEAR, int SM>
 __device__ __forceinline__ void lane_body(const SplatParams& p, const LaneParams& lp, long long linear_group, Hit* s_hit,
                                           SmallTile s_tile)
@@ -1083,35 +1156,7 @@ __device__ __forceinline__ void lane_body(const SplatParams& p, const LaneParams
             khi[r] = 0;
             if (mseg[r] != 0) {   // uniform
                 const int n = cn[r];
-                float len = 0.0f;   // polyline_kernel: diff = point[s] - point[s + 1], acc = fma(diff, diff, acc) per coordinate, sqrt
-                if (j + 1 < n)
-                    len = sqrtf(accv_poly::seg_length2_step(accv_poly::seg_length2_step(0.0f, qx[r] - nx[r]), qy[r] - ny[r]));
-                const float v0 = dpp_f<kDppQuad0>(len, len), v1 = dpp_f<kDppQuad1>(len, len), v2 = dpp_f<kDppQuad2>(len, len),
-                            v3 = dpp_f<kDppQuad3>(len, len);
-                const float chunk = ((v0 + v1) + v2) + v3;
-                const float total4 = lane_read(chunk, lb + ((j << 2) & (P2 - 1)));   // (every lane takes part in the exchange)
-                const float own = j < (P2 >> 2) ? total4 : 0.0f;
-                float incl = own;   // lanes j < P2 / 4 <= 16 of the block hold its totals; they sit in one row of 16
-                {
-                    float up = dpp_f<kDppRowShr + 1>(0.0f, incl);
-                    if (j >= 1) incl += up;
-                    up = dpp_f<kDppRowShr + 2>(0.0f, incl);
-                    if (j >= 2) incl += up;
-                    up = dpp_f<kDppRowShr + 4>(0.0f, incl);
-                    if (j >= 4) incl += up;
-                    up = dpp_f<kDppRowShr + 8>(0.0f, incl);
-                    if (j >= 8) incl += up;
-                }
-                const float excl = incl - own;
-                float base = lane_read(excl, lb + (j >> 2));
-                const int u4 = j & 3;
-                if (u4 >= 1) base += v0;
-                if (u4 >= 2) base += v1;
-                if (u4 >= 3) base += v2;
-                const float acc_next = base != 0.0f ? len + base : len;   // accum[j + 1]
-                const float up1 = dpp_f<kDppWaveShr1>(0.0f, acc_next);
-                acc[r] = j == 0 ? 0.0f : up1;                             // accum[j], valid for j < n
-                tot[r] = lane_read(acc[r], lb + max(n - 1, 0));
+                acc[r] = polyline_accumulate(qx[r], qy[r], nx[r], ny[r], n, j, lb, P2, tot[r]);
                 // the block's segments in reach -> its stretch of sample numbers
                 const unsigned long long pm = (mseg[r] >> lb) & p2_mask;
                 if (pm != 0) {
@@ -1139,34 +1184,8 @@ __device__ __forceinline__ void lane_body(const SplatParams& p, const LaneParams
                 const int k = min(k0, lp.S - 1);
                 const float frac = lp.S > 1 ? __fdiv_rn((float)k, s1) : 0.0f;
                 const float d = accv_poly::scale_query(frac, total);
-                // last point whose accumulated distance is <= d (polyline_kernel; all lanes stay in the loop for the exchanges)
-                int mn = 0, mx = max(n - 1, 0);
-                while (__ballot(act && mx - mn > 1)) {
-                    const int c = (mx + mn) >> 1;
-                    const float v = lane_read(A, lb + c);
-                    if (mx - mn > 1) {
-                        if (v < d) mn = c;
-                        else if (v > d) mx = c;
-                        else mn = mx = c;
-                    }
-                }
-                int idx = mn;
-                if (0.0f > d) idx = -1;
-                else if (total < d) idx = n - 1;
-                const int ia = min(max(idx, 0), max(n - 1, 0)), ic = min(ia + 1, max(n - 1, 0));
-                const float d0 = lane_read(A, lb + ia), d1 = lane_read(A, lb + ic);
-                const float pax = lane_read(ax, lb + ia), pay = lane_read(ay, lb + ia);
-                const float pcx = lane_read(ax, lb + ic), pcy = lane_read(ay, lb + ic);
-                float sx = pax, sy = pay;   // before the first / beyond the last point, or a segment shorter than epsilon
-                if (idx >= 0 && idx < n - 1) {
-                    const float seg_len = d1 - d0;
-                    if (seg_len >= 1.1920928955078125e-07f) {
-                        float w0, w1;
-                        accv_poly::lerp_weights(d, d0, d1, seg_len, w0, w1);
-                        sx = accv_poly::lerp_coord(pax, w0, pcx, w1);
-                        sy = accv_poly::lerp_coord(pay, w0, pcy, w1);
-                    }
-                }
+                float sx, sy;
+                polyline_sample_at(d, A, ax, ay, total, n, lb, act, sx, sy);
                 // sample -> target of this scale (cull_load<2>), runs of samples on one pixel are one splat
                 Cand c{(int)__fdiv_rn(sx, t.stride), (int)__fdiv_rn(sy, t.stride), t.radius, 0};
                 if ((sx != sx) || (sy != sy) || !act) c = Cand{0, 0, -1, 0};
@@ -1218,6 +1237,79 @@ __global__ __launch_bounds__(64) void lane_raster_multi_kernel(const FusedLanePa
     const int s = scale_of_group(fp.mp, blockIdx.x, first);
     const SplatParams p = preload_params(fp.mp.scale[s]);
     lane_body<CLEAR, SM>(p, fp.lp, (long long)blockIdx.x - first, s_hit, s_tile);
+}
+
+// ---------------------------------------------------------------- the polyline sampler as extra workgroups of the box-map launch
+// configs[3] prepares box maps AND lane maps every step: box maps (one launch), sampler (one launch, 5.9 us of which 4.4 us are
+// the launch itself), point splat (one launch).  The sampler's 256 workgroups are nothing next to the 11 456 tile waves of the box
+// maps, and nothing in the box-map launch depends on them — so they ride in it: workgroups [0, n_polylines) of
+// splat_multi_sampler_kernel sample one polyline each at wave level (polyline_accumulate / polyline_sample_at: bit for bit
+// polyline_kernel<f32, 256> for polylines of at most 64 points; fractions k / (S - 1); S a multiple of 64) and write the samples
+// and the bounding box of every 64 of them, exactly what accv_polyline_sample_boxes writes; the other workgroups are the tiles
+// of splat_multi_kernel.  The point splat that follows on the stream finds both.
+struct WaveSamplerParams {
+    const float2* points;      // [n_polylines, P]
+    const void* point_counts;  // [n_polylines] valid leading points (i32 / i64) or null = P
+    float2* samples;           // [n_polylines, S]
+    float4* boxes;             // [n_polylines * S / 64]
+    int n_polylines, P, S, counts_i64;
+};
+struct TargetsParams {
+    MultiParams mp;
+    WaveSamplerParams sp;
+};
+__device__ __forceinline__ void wave_sampler(const WaveSamplerParams& sp, int b)
+{
+    const int lane = threadIdx.x & 63;
+    int n = sp.P;
+    if (sp.point_counts) {
+        const long long c = sp.counts_i64 ? static_cast<const long long*>(sp.point_counts)[b]
+                                          : (long long)static_cast<const int*>(sp.point_counts)[b];
+        n = (int)max(0ll, min((long long)sp.P, c));
+    }
+    const float2 v = sp.points[(size_t)b * sp.P + min(lane, sp.P - 1)];
+    const float px = v.x, py = v.y;
+    float next_x = dpp_f<kDppWaveShl1>(px, px), next_y = dpp_f<kDppWaveShl1>(py, py);
+    if (!(lane + 1 < n)) {
+        next_x = px;
+        next_y = py;
+    }
+    float total;
+    const float acc = polyline_accumulate(px, py, next_x, next_y, n, lane, 0, 64, total);
+    float2* out = sp.samples + (size_t)b * sp.S;
+    const int groups = sp.S >> 6;
+    const float s1 = (float)(sp.S - 1), inf = __builtin_inff();
+    for (int k0 = 0; k0 < sp.S; k0 += 64) {
+        const int k = k0 + lane;
+        float sx = __builtin_nanf(""), sy = sx;   // a polyline without points: NaN everywhere (polyline_kernels.cuh:216-225)
+        if (n > 0) {   // uniform
+            const float d = accv_poly::scale_query(sp.S > 1 ? __fdiv_rn((float)k, s1) : 0.0f, total);
+            polyline_sample_at(d, acc, px, py, total, n, 0, true, sx, sy);
+        }
+        out[k] = float2{sx, sy};
+        const bool ok = sx == sx && sy == sy;
+        float x0 = ok ? sx : inf, y0 = ok ? sy : inf, x1 = ok ? sx : -inf, y1 = ok ? sy : -inf;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, sft));
+            y0 = fminf(y0, __shfl_xor(y0, sft));
+            x1 = fmaxf(x1, __shfl_xor(x1, sft));
+            y1 = fmaxf(y1, __shfl_xor(y1, sft));
+        }
+        if (lane == 0) sp.boxes[(size_t)b * groups + (k0 >> 6)] = make_float4(x0, y0, x1, y1);
+    }
+}
+template <bool CLEAR, int SM>
+__global__ __launch_bounds__(64) void splat_multi_sampler_kernel(const TargetsParams tp)
+{
+    if ((long long)blockIdx.x < (long long)tp.sp.n_polylines) {
+        wave_sampler(tp.sp, (int)blockIdx.x);
+        return;
+    }
+    const long long group = (long long)blockIdx.x - tp.sp.n_polylines;
+    long long first;
+    const int s = scale_of_group(tp.mp, group, first);
+    splat_body<4, 8, CLEAR, SM, 1, 1>(tp.mp.scale[s], group - first);
 }
 
 // bounding box (xmin, ymin, xmax, ymax) of every 64 consecutive points of points[b, :, :] (NaN points ignored; a group
@@ -1708,27 +1800,90 @@ int accv_draw_heatmap_batched_f32(float* heatmap, int batch, int num_classes, in
     return dispatch_splat(p, planes, clear, flags, stream, ev);
 }
 
+}  // extern "C"
+namespace {
+// box maps of all scales in one launch; with `sampler` the polyline sampler rides in the same launch (splat_multi_sampler_kernel)
+int draw_multiscale_impl(float* const* heatmaps, const int* heights, const int* widths, const float* strides, int num_scales,
+                         int batch, const float* centers_xy, const float* boxes_xyxy, const void* counts, int max_num_targets,
+                         float diameter_to_sigma_factor, float k_scale, unsigned flags, const WaveSamplerParams* sampler,
+                         hipStream_t stream);
+}
+extern "C" {
+
 int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights, const int* widths, const float* strides,
                                      int num_scales, int batch, const float* centers_xy, const float* boxes_xyxy,
                                      const void* counts, int max_num_targets, float diameter_to_sigma_factor,
                                      float k_scale, unsigned flags, void* stream_)
 {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return draw_multiscale_impl(heatmaps, heights, widths, strides, num_scales, batch, centers_xy, boxes_xyxy, counts,
+                                max_num_targets, diameter_to_sigma_factor, k_scale, flags, nullptr, static_cast<hipStream_t>(stream_));
+}
+
+int accv_draw_heatmap_multiscale_sample_f32(float* const* heatmaps, const int* heights, const int* widths, const float* strides,
+                                            int num_scales, int batch, const float* centers_xy, const float* boxes_xyxy,
+                                            const void* counts, int max_num_targets, float diameter_to_sigma_factor,
+                                            float k_scale, unsigned flags, const float* polylines_xy, int num_polylines,
+                                            int points, const void* point_counts, int num_samples, float* samples,
+                                            float* group_boxes, void* stream_)
+{
+    if (num_polylines < 0) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale_sample: negative polyline count");
+    if (points < 1 || points > 64)
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale_sample: 1..64 points per polyline (wave-level sampler), got %d",
+                          points);
+    if (num_samples < 64 || num_samples % 64 != 0 || num_samples > (1 << 20))
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale_sample: the number of samples must be a multiple of 64 up to 2^20 "
+                                       "(one group box per 64 samples), got %d", num_samples);
+    if (num_polylines > 0 && (!polylines_xy || !samples || !group_boxes))
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale_sample: null polylines / samples / group_boxes");
+    if ((reinterpret_cast<uintptr_t>(polylines_xy) & 7u) || (reinterpret_cast<uintptr_t>(samples) & 7u) ||
+        (reinterpret_cast<uintptr_t>(group_boxes) & 15u))
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale_sample: polylines / samples need 8-byte, group boxes 16-byte alignment");
+    WaveSamplerParams sp{};
+    sp.points = reinterpret_cast<const float2*>(polylines_xy);
+    sp.point_counts = point_counts;
+    sp.samples = reinterpret_cast<float2*>(samples);
+    sp.boxes = reinterpret_cast<float4*>(group_boxes);
+    sp.n_polylines = num_polylines;
+    sp.P = points;
+    sp.S = num_samples;
+    sp.counts_i64 = (flags & ACCV_HM_POINT_COUNTS_I64) ? 1 : 0;
+    return draw_multiscale_impl(heatmaps, heights, widths, strides, num_scales, batch, centers_xy, boxes_xyxy, counts,
+                                max_num_targets, diameter_to_sigma_factor, k_scale, flags, num_polylines > 0 ? &sp : nullptr,
+                                static_cast<hipStream_t>(stream_));
+}
+
+}  // extern "C"
+namespace {
+int draw_multiscale_impl(float* const* heatmaps, const int* heights, const int* widths, const float* strides, int num_scales,
+                         int batch, const float* centers_xy, const float* boxes_xyxy, const void* counts, int max_num_targets,
+                         float diameter_to_sigma_factor, float k_scale, unsigned flags, const WaveSamplerParams* sampler,
+                         hipStream_t stream)
+{
     (void)take_launch_events();   // a pending accv_draw_heatmap_time_next_launch pair is dropped, not kept for a later call
+    // the sampler's workgroups alone: whenever the box maps have nothing to launch
+    auto sampler_only = [&]() -> int {
+        if (!sampler) return ACCV_OK;
+        TargetsParams tp{};
+        tp.sp = *sampler;
+        seal_tile_prefix(tp.mp);
+        hipLaunchKernelGGL((splat_multi_sampler_kernel<true, 0>), dim3((unsigned)sampler->n_polylines), dim3(64), 0, stream, tp);
+        note_dispatch("splat_multi_sampler_kernel", 4, 8, true, 0, dim3((unsigned)sampler->n_polylines), dim3(64));
+        return accv::check_launch("draw_heatmap multi-scale splat + sampler kernel");
+    };
     if (num_scales < 1 || num_scales > kMaxScales)
         return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: 1..%d scales supported, got %d", kMaxScales, num_scales);
     if (!heatmaps || !heights || !widths || !strides) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: null array");
     if (batch < 0 || max_num_targets < 0) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: negative count");
     if (max_num_targets > (1 << 30))
         return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: more than 2^30 objects per sample");
-    if (batch == 0) return ACCV_OK;
+    if (batch == 0) return sampler_only();
     if (!counts) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: counts pointer is null");
     if (max_num_targets > 0 && (!centers_xy || !boxes_xyxy))
         return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: null object array");
     if ((reinterpret_cast<uintptr_t>(boxes_xyxy) & 15u) || (reinterpret_cast<uintptr_t>(centers_xy) & 7u))
         return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: centres need 8-byte and boxes 16-byte alignment");
     const bool clear = (flags & ACCV_HM_CLEAR) != 0;
-    if (max_num_targets == 0 && !clear) return ACCV_OK;
+    if (max_num_targets == 0 && !clear) return sampler_only();
 
     MultiParams mp{};
     long long tiles = 0;
@@ -1765,12 +1920,32 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
     }
     mp.n_scales = used;
     mp.tile_begin[used] = tiles;
-    if (used == 0 || tiles == 0) return ACCV_OK;
-    if (tiles > INT_MAX) return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: %lld tiles exceed the grid limit", tiles);
+    if (used == 0 || tiles == 0) return sampler_only();
+    if (tiles + (sampler ? sampler->n_polylines : 0) > INT_MAX)
+        return accv::fail(ACCV_EINVAL, "draw_heatmap_multiscale: %lld tiles exceed the grid limit", tiles);
     if (!(flags & ACCV_HM_CALLER_SCALE_ORDER)) coarse_scales_first(mp);
     seal_tile_prefix(mp);
     int nt = accv::tune_get("hm_nt", -1);
     if (nt < 0) nt = (flags & ACCV_HM_WRITE_THROUGH) ? 4 : 0;   // same store policy as the single-scale path
+    if (sampler) {
+        TargetsParams tp{};
+        tp.mp = mp;
+        tp.sp = *sampler;
+        const dim3 grid((unsigned)(tiles + sampler->n_polylines)), block(64);
+        if (clear) {
+            if (nt >= 2)
+                hipLaunchKernelGGL((splat_multi_sampler_kernel<true, 4>), grid, block, 0, stream, tp);
+            else
+                hipLaunchKernelGGL((splat_multi_sampler_kernel<true, 0>), grid, block, 0, stream, tp);
+        } else {
+            if (nt >= 2)
+                hipLaunchKernelGGL((splat_multi_sampler_kernel<false, 4>), grid, block, 0, stream, tp);
+            else
+                hipLaunchKernelGGL((splat_multi_sampler_kernel<false, 0>), grid, block, 0, stream, tp);
+        }
+        note_dispatch("splat_multi_sampler_kernel", 4, 8, clear, nt >= 2 ? 4 : 0, grid, block);
+        return accv::check_launch("draw_heatmap multi-scale splat + sampler kernel");
+    }
     const dim3 grid((unsigned)tiles), block(64);
     if (clear) {
         if (nt >= 2)
@@ -1786,6 +1961,9 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
     note_dispatch("splat_multi_kernel", 4, 8, clear, nt >= 2 ? 4 : 0, grid, block);
     return accv::check_launch("draw_heatmap multi-scale splat kernel");
 }
+}  // namespace
+extern "C" {
+
 
 size_t accv_draw_points_workspace_bytes(int batch, int num_points)
 {

@@ -130,7 +130,7 @@ def config2(n=10_000):
 
 def config3():
     from accvlab.batching_helpers import combine_data
-    from accvlab.draw_heatmap import draw_heatmap_multiscale, draw_polylines_multiscale
+    from accvlab.draw_heatmap import draw_heatmap_multiscale, draw_polylines_multiscale, draw_targets_multiscale
     from accvlab import _amd_native as nat
     from oracle import h1 as oracle
 
@@ -156,12 +156,16 @@ def config3():
     ys = SH * (1 - 0.9 * t_).expand(B, L, P)
     lanes = torch.stack([xs, ys], -1).to(dev)
 
-    def step():
+    def step():      # box maps + lane maps of one step: two launches (the sampler rides in the box-map launch)
+        draw_targets_multiscale(maps, crb, brb, strides, lane_maps, lanes, 256, 2, None, 6.0, 1.0, clear=True)
+
+    def step_separate():      # the two operators one after the other: three launches
         draw_heatmap_multiscale(maps, crb, brb, strides, 6.0, 1.0, clear=True)
         draw_polylines_multiscale(lane_maps, lanes, 256, 2, strides, clear=True)
 
     sync = torch.cuda.synchronize
     t = _best_of(step, 300, 500, sync)
+    t_separate = _best_of(step_separate, 300, 500, sync)
 
     def events_ms(fn, warm=100, iters=300):      # HIP events on the launch stream (torch's current stream); faster of two blocks
         best = None
@@ -210,13 +214,16 @@ def config3():
     t_cpu = time.perf_counter() - t0
     return _line(metric="multi-scale target maps + lane raster (frames/s), 3840x2160 source, strides 4/8/16", value=B / t, unit="frames/s",
           steps=500, warmup=300, ms_per_step=t * 1e3, dtype="f32",
-          config={"workload": "configs[3]: batch 32, box maps at strides 4/8/16 from float boxes (1 launch, draw_heatmap_multiscale) + "
-                              "lane maps from 8 polylines x 24 points, 256 samples, radius 2 (2 launches, draw_polylines_multiscale)"},
+          config={"workload": "configs[3]: batch 32, box maps at strides 4/8/16 from float boxes + lane maps from 8 polylines x 24 points, "
+                              "256 samples, radius 2: draw_targets_multiscale, 2 launches (box maps with the polyline sampler riding "
+                              "in the launch; point splat)"},
           roofline={"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_GBPS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_GBPS,
                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": nbytes,
-                    "note": "three launches over 2 x 87 MB of maps (box maps + lane maps); the faster of two timed blocks of 500 steps, each behind "
+                    "note": "two launches over 2 x 87 MB of maps (box maps + lane maps); the faster of two timed blocks of 500 steps, each behind "
                             "300 warm-up steps"},
-          secondary={"box_maps_only_ms": t_boxes * 1e3, "box_maps_only_frames_per_s": B / t_boxes,
+          secondary={"separate_operators_ms": t_separate * 1e3, "separate_operators_frames_per_s": B / t_separate,
+                     "separate_operators_note": "draw_heatmap_multiscale + draw_polylines_multiscale, three launches (same maps, bit for bit)",
+                     "box_maps_only_ms": t_boxes * 1e3, "box_maps_only_frames_per_s": B / t_boxes,
                      "box_maps_only_frac": map_bytes / t_boxes / 1e9 / HBM_GBPS,
                      "lane_raster_only_ms": t_lanes * 1e3, "lane_raster_only_frac": map_bytes / t_lanes / 1e9 / HBM_GBPS,
                      "lane_raster_kernel": k_lanes, "map_bytes_per_call": map_bytes,

@@ -103,6 +103,23 @@ int accv_draw_heatmap_multiscale_f32(float* const* heatmaps, const int* heights,
                                      const void* counts, int max_num_targets, float diameter_to_sigma_factor,
                                      float k_scale, unsigned flags, void* stream);
 
+/* accv_draw_heatmap_multiscale_f32 with the polyline sampler riding in the same launch (BASELINE config 3 prepares box maps and
+ * lane maps every step; the sampler's few hundred workgroups cost nothing next to the box maps' tiles, a launch of their own
+ * costs 5.9 us).  The first 13 arguments are those of accv_draw_heatmap_multiscale_f32 and mean the same; in addition
+ * polylines_xy f32[num_polylines, points, 2] (1..64 points; point_counts[num_polylines] valid leading points, int32 or int64
+ * with ACCV_HM_POINT_COUNTS_I64, null = all) are sampled at the num_samples (a multiple of 64) arc-length fractions
+ * k / (num_samples - 1) into samples f32[num_polylines, num_samples, 2], and the bounding box of every 64 consecutive samples
+ * goes to group_boxes f32[num_polylines * num_samples / 64, 4] — what accv_polyline_sample_boxes writes for relative distances
+ * = those fractions (polyline_common.cuh:58-163 semantics; finite samples and boxes bit for bit, NaN samples are NaN with an
+ * unspecified sign bit), i.e. the input of
+ * accv_draw_points_multiscale_f32 with ACCV_HM_GROUP_BOXES_GIVEN, which follows on the same stream. */
+int accv_draw_heatmap_multiscale_sample_f32(float* const* heatmaps, const int* heights, const int* widths, const float* strides,
+                                            int num_scales, int batch, const float* centers_xy, const float* boxes_xyxy,
+                                            const void* counts, int max_num_targets, float diameter_to_sigma_factor,
+                                            float k_scale, unsigned flags, const float* polylines_xy, int num_polylines,
+                                            int points, const void* point_counts, int num_samples, float* samples,
+                                            float* group_boxes, void* stream);
+
 /* Lane raster of all scales in TWO launches (BASELINE config 3): sampled polyline points f32[batch, N, 2]
  * (source pixels; output of accv_polyline_sample, NaN = sample of an empty polyline) are drawn into every
  * heatmaps[s] f32[batch, heights[s], widths[s]] as Gaussians of `radius` around int(p / strides[s]) — for each scale the

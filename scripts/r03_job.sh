@@ -4,17 +4,6 @@ ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/r03"
 mkdir -p "$OUT"
 cd "$ROOT"
-timeout -k 10 600 python -m pytest tests/test_lane_raster_fused_gpu.py tests/test_lane_raster_gpu.py tests/test_multiscale_gpu.py tests/test_config_sizes_gpu.py tests/test_draw_heatmap_gpu.py tests/test_guard_bands_gpu.py -m gpu -x -q > "$OUT/prologue_tests.log" 2>&1; rc=$?; tail -5 "$OUT/prologue_tests.log" | cut -c1-300; [ $rc -eq 0 ] || exit 1
-timeout -k 10 400 python scripts/lane_points_probe.py --alt-lib accv-lab_amd/accvlab/_amd_native/libaccv_hip_prev.so > "$OUT/lane_points_probe_chain2.log" 2>&1; echo "[r03] rc=$?"
-python - <<'PY'
-import json
-for l in open('gpurun_out/r03/lane_points_probe_chain2.log'):
-    l=l.strip()
-    if not l.startswith('{'): continue
-    d=json.loads(l)
-    print(d['scales'], {k:(v['shipped']['us'],v['prev']['us'],v['prev'].get('same_as_shipped')) for k,v in d.items() if isinstance(v,dict) and 'shipped' in v})
-PY
-timeout -k 10 400 python scripts/small_splat_probe.py accv-lab_amd/accvlab/_amd_native/libaccv_hip_prev.so > "$OUT/small_splat_chain2.log" 2>&1; echo "[r03] rc=$?"
-cut -c1-300 "$OUT/small_splat_chain2.log"
-timeout -k 10 200 python scripts/bench_configs.py 3 > "$OUT/c3_chain2.json" 2>/dev/null; python -c "
-import json; d=json.loads(open('$OUT/c3_chain2.json').read().strip().splitlines()[-1]); print(d['value'], json.dumps(d.get('breakdown'))[:500])"
+timeout -k 10 600 python -m pytest tests/test_targets_multiscale_gpu.py tests/test_multiscale_gpu.py tests/test_lane_raster_gpu.py tests/test_lane_raster_fused_gpu.py -m gpu -x -q > "$OUT/targets_tests.log" 2>&1; rc=$?; tail -25 "$OUT/targets_tests.log" | cut -c1-300; [ $rc -eq 0 ] || exit 1
+timeout -k 10 200 python scripts/bench_configs.py 3 > "$OUT/c3_targets.json" 2>/dev/null; python -c "
+import json; d=json.loads(open('$OUT/c3_targets.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], json.dumps(d.get('secondary'))[:900])"
