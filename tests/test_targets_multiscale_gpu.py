@@ -60,10 +60,11 @@ def test_targets_equal_the_two_operators(ragged, clear, l, p, q, radius):
     box_b, lane_b = [t.clone() for t in base], [t.clone() for t in base]
     draw_targets_multiscale(box_a, centers, boxes, strides, lane_a, pts, q, radius, None, 6.0, 0.9, num_points=npts,
                             num_lanes=nlanes, clear=clear)
-    last = nat.last_dispatch()
+    assert "splat_points_multi_kernel" in nat.last_dispatch() or p > 64 or q % 64      # (else: the per-scale / two-launch paths)
     draw_heatmap_multiscale(box_b, centers, boxes, strides, 6.0, 0.9, clear=clear)
     draw_polylines_multiscale(lane_b, pts, q, radius, strides, 6.0, 0.9, num_points=npts, num_lanes=nlanes, clear=clear)
-    assert last.split(" ")[0] == nat.last_dispatch().split(" ")[0]       # the lane maps come from the same kernel either way
+    if (l, p, q) == (2, 24, 256):     # a sparse lane set: alone it takes the one-launch lane raster, inside the step the rider
+        assert "lane_raster_multi_kernel" in nat.last_dispatch()
     for i in range(len(strides)):
         assert torch.equal(box_a[i], box_b[i]), f"box map {i}"
         assert torch.equal(lane_a[i], lane_b[i]), f"lane map {i}"
