@@ -19,7 +19,8 @@ def main(out, filters=("splat_kernel<",)):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(files[0])):
             if any(f in r["Kernel_Name"] for f in filters):
-                agg[(r["Kernel_Name"].split("(anonymous namespace)::")[-1][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
+                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                agg[(name[:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in agg.items():
             res.setdefault(k, {})[c] = sum(v) / len(v)
             res[k]["launches_sampled"] = len(v)
