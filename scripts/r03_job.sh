@@ -1,3 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p gpurun_out/r03
-timeout -k 10 300 python scripts/targets_sparse_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03/targets_sparse_probe.log
+for i in 1 2; do
+for lib in "" accv-lab_amd/accvlab/_amd_native/libaccv_hip_multipre.so; do
+ACCV_HIP_LIB=$lib timeout -k 10 200 python scripts/bench_configs.py 3 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['secondary']; print('$lib'[-22:] or 'shipped', round(d['ms_per_step']*1e3,2), 'box', round(s['box_maps_only_ms']*1e3,2), 'lanes', round(s['lane_raster_only_ms']*1e3,2), 'separate', round(s['separate_operators_ms']*1e3,2))"
+done; done
