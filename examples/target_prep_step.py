@@ -3,7 +3,7 @@
     DataLoader worker      per-frame meta data (boxes, labels, lanes) -> packing_collate: ONE buffer per batch
     multi_tensor_copier    start_copy(packed, "cuda") on the side stream, overlapping the previous step's kernels
     batching_helpers       combine_data: ragged lists -> RaggedBatch (boxes / centres / labels)
-    draw_heatmap           draw_heatmap_multiscale (boxes, strides 4/8/16) + draw_polylines_multiscale (lanes)
+    draw_heatmap           draw_targets_multiscale: box maps (strides 4/8/16) + lane maps in two launches
     batching_helpers       batched_bool_indexing / batched_indexing_access on the loss side
 
 Used by tests/test_pipeline_gpu.py, which checks every stage against the CPU oracle; run it directly for timings.
@@ -21,7 +21,7 @@ from typing import Dict, List
 import torch
 
 import accvlab.batching_helpers as bh
-from accvlab.draw_heatmap import draw_heatmap_multiscale, draw_polylines_multiscale
+from accvlab.draw_heatmap import draw_targets_multiscale
 from accvlab.multi_tensor_copier import packing_collate, start_copy
 
 STRIDES = (4.0, 8.0, 16.0)
@@ -68,8 +68,8 @@ def prepare_targets(samples, targets, device):
     boxes = bh.combine_data([s["boxes"] for s in samples], other_with_same_sample_sizes=centers)
     labels = bh.combine_data([s["labels"] for s in samples], other_with_same_sample_sizes=centers)
     lanes = torch.stack([s["lanes"] for s in samples])
-    draw_heatmap_multiscale(targets["objects"], centers, boxes, STRIDES, clear=True)
-    draw_polylines_multiscale(targets["lanes"], lanes, 128, 2, STRIDES, clear=True)
+    # (= draw_heatmap_multiscale + draw_polylines_multiscale; the polyline sampler rides in the box-map launch)
+    draw_targets_multiscale(targets["objects"], centers, boxes, STRIDES, targets["lanes"], lanes, 128, 2, clear=True)
     # loss side: keep the objects of class 0..2 ("vehicles"), compacted, without a host synchronisation
     keep = bh.RaggedBatch(labels.tensor < 3, sample_sizes=labels.sample_sizes)
     vehicles = bh.batched_bool_indexing(boxes, keep, max_sample_size=boxes.tensor.shape[1])
