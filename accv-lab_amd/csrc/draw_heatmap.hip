@@ -34,6 +34,11 @@
 #include "accv_common.h"
 #include "polyline_arith.h"
 
+#ifndef ACCV_BOX_TILE_R
+#define ACCV_BOX_TILE_R 8   // rows per half-wave of a box-map tile (multi-scale launches): 128 x 16 pixel tiles.  4 = 128 x 8 tiles
+                            // (54 VGPRs, 8 waves per SIMD, twice the waves): box maps of config 3 17.1 -> 18.4 us, measured
+#endif
+
 namespace {
 
 constexpr int kWavesPerGroup = 1;  // 1 wave per workgroup measured 6.5 % faster than 4 (profiles/r01_h1_variants_wpg.log)
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(64) void splat_multi_kernel(const MultiParams mp)
     const int s = scale_of_group(mp, blockIdx.x, first);
     // (the scale's parameters are NOT requested up front here, neither as copies (preload_params) nor as asm inputs: either way
     // the register-bound tile body goes from 79 to 85-124 VGPRs and loses one or two waves per SIMD)
-    splat_body<4, 8, CLEAR, SM, 1, 1>(mp.scale[s], (long long)blockIdx.x - first);
+    splat_body<4, ACCV_BOX_TILE_R, CLEAR, SM, 1, 1>(mp.scale[s], (long long)blockIdx.x - first);
 }
 
 // ---------------------------------------------------------------- small splats (lane rasters, point-like targets)
@@ -1309,7 +1314,7 @@ __global__ __launch_bounds__(64) void splat_multi_sampler_kernel(const TargetsPa
     const long long group = (long long)blockIdx.x - tp.sp.n_polylines;
     long long first;
     const int s = scale_of_group(tp.mp, group, first);
-    splat_body<4, 8, CLEAR, SM, 1, 1>(tp.mp.scale[s], group - first);
+    splat_body<4, ACCV_BOX_TILE_R, CLEAR, SM, 1, 1>(tp.mp.scale[s], group - first);
 }
 
 // bounding box (xmin, ymin, xmax, ymax) of every 64 consecutive points of points[b, :, :] (NaN points ignored; a group
@@ -1911,7 +1916,7 @@ int draw_multiscale_impl(float* const* heatmaps, const int* heights, const int* 
         p.boxes_f = boxes_xyxy;
         p.stride = strides[i];
         p.tiles_x = (p.W + 127) / 128;
-        p.tiles_y = (p.H + 15) / 16;
+        p.tiles_y = (p.H + 2 * ACCV_BOX_TILE_R - 1) / (2 * ACCV_BOX_TILE_R);
         p.n_tiles = (long long)batch * p.tiles_x * p.tiles_y;
         p.grid3d = 0;
         mp.tile_begin[used] = tiles;
