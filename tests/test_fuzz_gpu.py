@@ -421,6 +421,63 @@ def test_multiscale_and_lane_raster_random_against_the_per_scale_operators(seed)
             assert torch.equal(fused[i], ref), f"lane raster {seed}/{case} stride {s} shape {shapes[i]} q {q} r {radius}"
 
 
+@pytest.mark.parametrize("seed", _seeds(8))
+def test_lane_raster_paths_agree_on_random_shapes(seed):
+    """the three ways to the lane maps — the one-launch kernel (tile waves sample the polylines), sampler + point splat, and the
+    step operator draw_targets_multiscale (sampler riding in the box-map launch) — bit for bit on random shapes: 1..64 points,
+    1..16 polylines per frame, 1..400 samples, ragged counts, non-finite vertices, clear and in place"""
+    from accvlab import _amd_native as nat
+    from accvlab.batching_helpers import combine_data
+    from accvlab.draw_heatmap import draw_heatmap_multiscale, draw_polylines_multiscale, draw_targets_multiscale, lanes as lanes_mod
+
+    rng = np.random.default_rng(424200 + seed)
+    seen = set()
+    for case in range(6):
+        b = int(rng.integers(1, 4))
+        sw, sh = float(rng.choice([512, 1024, 2048, 4000])), float(rng.choice([256, 512, 1080]))
+        n_scales = int(rng.integers(1, 4))
+        strides = [float(x) for x in rng.choice([1.0, 2.0, 4.0, 8.0, 16.0], size=n_scales, replace=False)]
+        strides = [s_ for s_ in strides if sw / s_ * sh / s_ * 4 * b < 3e8] or [8.0]
+        clear = bool(rng.integers(0, 2))
+        nl, npnt = int(rng.choice([1, 2, 3, 5, 8, 16])), int(rng.choice([1, 2, 3, 8, 17, 24, 33, 64]))
+        q, radius = int(rng.choice([1, 2, 17, 64, 100, 128, 256, 400])), int(rng.integers(0, 6))
+        start = rng.uniform([0, 0], [sw, sh], size=(b, nl, 1, 2))
+        steps = rng.normal(0, 1, size=(b, nl, npnt, 2)) * [sw / npnt / 2, sh / npnt / 2] + [sw / npnt / 3, -sh / npnt / 4]
+        pts = (start + np.cumsum(steps, axis=2)).astype(np.float32)
+        for _ in range(int(rng.integers(0, 3))):      # a few non-finite / huge vertices
+            pts[rng.integers(0, b), rng.integers(0, nl), rng.integers(0, npnt), rng.integers(0, 2)] = \
+                rng.choice([np.nan, np.inf, -np.inf, 3.0e7, -1.0e12])
+        pts_d = torch.from_numpy(pts).to(DEV)
+        ragged = bool(rng.integers(0, 2))
+        npts = torch.from_numpy(rng.integers(0, npnt + 1, size=(b, nl)).astype(rng.choice([np.int32, np.int64]))).to(DEV) if ragged else None
+        nlanes = torch.from_numpy(rng.integers(0, nl + 1, size=(b,)).astype(rng.choice([np.int32, np.int64]))).to(DEV) if ragged else None
+        g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+        shapes = [(b, max(1, int(sh / s_)) , max(4, int(sw / s_) // 4 * 4)) for s_ in strides]
+        base = [(torch.rand(s_, generator=g) * 0.3).to(DEV) for s_ in shapes]
+        kw = dict(num_points=npts, num_lanes=nlanes, clear=clear)
+        one = [t.clone() for t in base]
+        draw_polylines_multiscale(one, pts_d, q, radius, strides, 6.0, 0.9, **kw)
+        seen.add(nat.last_dispatch().split("<")[0])
+        two = [t.clone() for t in base]
+        lanes_mod.FUSED_SAMPLER = False
+        try:
+            draw_polylines_multiscale(two, pts_d, q, radius, strides, 6.0, 0.9, **kw)
+        finally:
+            lanes_mod.FUSED_SAMPLER = True
+        cs = [torch.rand(int(rng.integers(0, 12)), 2, generator=g) * torch.tensor([sw, sh]) for _ in range(b)]
+        crb = combine_data(cs, device=DEV)
+        brb = combine_data([torch.cat([c - 20.0, c + 30.0], 1) for c in cs], device=DEV, other_with_same_sample_sizes=crb)
+        box_a, lane_a = [t.clone() for t in base], [t.clone() for t in base]
+        draw_targets_multiscale(box_a, crb, brb, strides, lane_a, pts_d, q, radius, None, 6.0, 0.9, **kw)
+        box_b = [t.clone() for t in base]
+        draw_heatmap_multiscale(box_b, crb, brb, strides, 6.0, 0.9, clear=clear)
+        what = f"{seed}/{case}: b {b} lanes {nl} x {npnt} points, {q} samples, r {radius}, strides {strides}, clear {clear}, ragged {ragged}"
+        for i in range(len(strides)):
+            assert torch.equal(one[i], two[i]), f"default path vs sampler + point splat, scale {i}, {what}"
+            assert torch.equal(lane_a[i], two[i]), f"draw_targets_multiscale lane map, scale {i}, {what}"
+            assert torch.equal(box_a[i], box_b[i]), f"draw_targets_multiscale box map, scale {i}, {what}"
+
+
 @pytest.mark.parametrize("seed", _seeds(6))
 def test_h2_random_gradients_against_torch_autograd(seed):
     """backward of gather (repeated indices accumulate), inverse, write and mapping against the same expressions written with torch
