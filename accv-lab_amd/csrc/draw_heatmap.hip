@@ -261,10 +261,19 @@ __device__ __forceinline__ unsigned long long cull_round(const TileCtx& t, int b
 
 // hit record of a lane that passed the cull: the exact clipped box of the reference (left/right/top/bottom,
 // cuh:64-67, 92-95; 64-bit), relative to the tile and clamped to it; an empty exact box masks every pixel
-__device__ __forceinline__ Hit make_hit(const SplatParams& p, const TileCtx& t, int x, int y, int r)
+__device__ __forceinline__ float hit_exponent_scale(const SplatParams& p, int r)   // log2(e) / (2 sigma^2), sigma = diameter / factor
 {
     const float sigma = (float)(2 * r + 1) / p.factor;
-    const float c2 = kLog2e / (2.0f * sigma * sigma);
+    return kLog2e / (2.0f * sigma * sigma);
+}
+__device__ __forceinline__ Hit make_hit(const SplatParams& p, const TileCtx& t, int x, int y, int r, float c2);
+__device__ __forceinline__ Hit make_hit(const SplatParams& p, const TileCtx& t, int x, int y, int r)
+{
+    return make_hit(p, t, x, y, r, hit_exponent_scale(p, r));
+}
+// (c2 given: point splats share one radius, and the two IEEE divisions behind it were repeated per lane and fetched group)
+__device__ __forceinline__ Hit make_hit(const SplatParams& p, const TileCtx& t, int x, int y, int r, float c2)
+{
     const long long x0 = (long long)x - min(x, r), x1 = (long long)x + min((long long)p.W - x, (long long)r + 1);
     const long long y0 = (long long)y - min(y, r), y1 = (long long)y + min((long long)p.H - y, (long long)r + 1);
     const long long xlo = max(x0, (long long)t.tx0) - t.tx0, xhi = min(x1, (long long)t.tx1) - t.tx0;
@@ -682,9 +691,21 @@ __device__ __forceinline__ float2 request_group_samples(const TileCtx& t, int su
 }
 // ... and its target at this scale, exactly cull_load<2>; consecutive samples that land on the same pixel are one and the same
 // splat (coarse scales see several samples per pixel): the first of a run is kept, results are unchanged
-__device__ __forceinline__ Cand group_candidates(const TileCtx& t, const float2 c, int lane)
+// x / stride, exactly: for a stride that is a power of two the product with its reciprocal is the same correctly rounded
+// value as the IEEE division (both round x * 2^-k once) and costs one instruction instead of a dozen
+struct PixelScale {
+    float stride, inv;
+    bool pow2;   // wave-uniform
+};
+__device__ __forceinline__ PixelScale pixel_scale(float stride)
 {
-    Cand out{(int)__fdiv_rn(c.x, t.stride), (int)__fdiv_rn(c.y, t.stride), t.radius, 0};
+    const bool pow2 = (__float_as_uint(stride) & 0x007fffffu) == 0u && stride > 1.0e-30f && stride < 1.0e30f;
+    return PixelScale{stride, pow2 ? 1.0f / stride : 0.0f, pow2};
+}
+__device__ __forceinline__ float to_pixels(float x, const PixelScale& ps) { return ps.pow2 ? x * ps.inv : __fdiv_rn(x, ps.stride); }
+__device__ __forceinline__ Cand group_candidates(const TileCtx& t, const PixelScale& ps, const float2 c, int lane)
+{
+    Cand out{(int)to_pixels(c.x, ps), (int)to_pixels(c.y, ps), t.radius, 0};
     if ((c.x != c.x) || (c.y != c.y)) out = Cand{0, 0, -1, 0};
     const int nx = dpp_i<kDppWaveShr1>(0, out.x), ny = dpp_i<kDppWaveShr1>(0, out.y), nr = dpp_i<kDppWaveShr1>(-2, out.r);
     if (lane > 0 && nx == out.x && ny == out.y && nr == out.r) out.r = -1;
@@ -800,6 +821,8 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
         // walked candidate by candidate — a tile crossed by a lane visits 1-3 rounds instead of all of them
         const int rc = min(max(t.radius, 0), 1 << 30);
         const int rows_hint = 2 * min(rc, 64) + 1;   // every sample has the same radius: no clipped box is taller
+        const float c2_tile = hit_exponent_scale(p, t.radius);   // ... and the same exponent scale
+        const PixelScale ps = pixel_scale(t.stride);
         const ReachBounds rb = reach_bounds(t, rc, t.tx0, t.tx1, t.ty0, t.ty1);
         for (int g0 = 0; g0 < p.n_groups; g0 += kCand) {
             unsigned long long mg = __ballot(group_reaches(g0 == 0 ? load_group_box<true>(p, t, lane) : load_group_box(p, t, g0 + lane), rb));
@@ -832,7 +855,7 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
                 if constexpr (NW > 1) prepare_tile();
 #pragma unroll
                 for (int u = 0; u < kFetch; ++u)
-                    if (sub_base[u] >= 0) cand[u] = group_candidates(t, raw[u], lane);
+                    if (sub_base[u] >= 0) cand[u] = group_candidates(t, ps, raw[u], lane);
                 // Round 3: the hits of the (up to four) fetched groups go into ONE list and are walked together when they fit
                 // it — a tile of a coarse scale is crossed by several lanes, each contributing a handful of samples per
                 // group, and one compaction + one walk replaces four dependent ballot / LDS / fence / walk rounds
@@ -850,7 +873,8 @@ __device__ __forceinline__ void small_body(const SplatParams& p, long long linea
 #pragma unroll
                     for (int u = 0; u < kFetch; ++u) {
                         if ((mm[u] >> lane) & 1ull)
-                            s_hit[wave][at + __popcll(mm[u] & ((1ull << lane) - 1ull))] = make_hit(p, t, cand[u].x, cand[u].y, cand[u].r);
+                            s_hit[wave][at + __popcll(mm[u] & ((1ull << lane) - 1ull))] =
+                                make_hit(p, t, cand[u].x, cand[u].y, cand[u].r, c2_tile);
                         at += __popcll(mm[u]);
                     }
                     walk_hits<(NW > 1)>(p, t, lane, total, s_hit[wave], s_tile, rows_hint);
@@ -1092,6 +1116,8 @@ __device__ __forceinline__ void lane_body(const SplatParams& p, const LaneParams
     const unsigned long long p2_mask = P2 == 64 ? ~0ull : ((1ull << P2) - 1ull);
     const int rc = min(max(t.radius, 0), 1 << 30);
     const int rows_hint = 2 * min(rc, 64) + 1;
+    const float c2_tile = hit_exponent_scale(p, t.radius);
+    const PixelScale ps = pixel_scale(t.stride);
     ReachBounds rb = reach_bounds(t, rc, t.tx0, t.tx1, t.ty0, t.ty1);
     rb.xlo -= 1.0f;   // the interpolation's products round: a sample can leave its segment's box by 4e-7 of the coordinates
     rb.ylo -= 1.0f;
@@ -1192,7 +1218,7 @@ __device__ __forceinline__ void lane_body(const SplatParams& p, const LaneParams
                 float sx, sy;
                 polyline_sample_at(d, A, ax, ay, total, n, lb, act, sx, sy);
                 // sample -> target of this scale (cull_load<2>), runs of samples on one pixel are one splat
-                Cand c{(int)__fdiv_rn(sx, t.stride), (int)__fdiv_rn(sy, t.stride), t.radius, 0};
+                Cand c{(int)to_pixels(sx, ps), (int)to_pixels(sy, ps), t.radius, 0};
                 if ((sx != sx) || (sy != sy) || !act) c = Cand{0, 0, -1, 0};
                 const int ux = dpp_i<kDppWaveShr1>(0, c.x), uy = dpp_i<kDppWaveShr1>(0, c.y), ur = dpp_i<kDppWaveShr1>(-1, c.r);
                 if (j > 0 && ux == c.x && uy == c.y && ur == c.r) c.r = -1;
@@ -1208,7 +1234,7 @@ __device__ __forceinline__ void lane_body(const SplatParams& p, const LaneParams
                     walk_hits<false>(p, t, lane, list_n, s_hit, s_tile, rows_hint);
                     list_n = 0;
                 }
-                if (in) s_hit[list_n + __popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, c.x, c.y, c.r);
+                if (in) s_hit[list_n + __popcll(m & ((1ull << lane) - 1ull))] = make_hit(p, t, c.x, c.y, c.r, c2_tile);
                 list_n += nh;
             }
         }
