@@ -101,9 +101,15 @@ __device__ __forceinline__ long long load_count(const void* p, long long i, int 
 }
 
 // THREADS = workgroup size: 256, or 1024 for long polylines (the scan over the points is the serial part of a workgroup)
-template <int TY, int THREADS>
+// DC = number of coordinates per point when it is 2 or 3 (compile-time), 0 = p.D at run time.  With a run-time D every loop
+// over the coordinates is a real loop with its loads and a wait inside: a segment's length cost D dependent round trips to
+// memory, and the four segments a thread takes per trip cost 4 D of them one after the other (5000 2-D points on 1024 threads:
+// 16 round trips in front of the scan; ISA of round 2's kernel) — with DC the loops unroll and the loads of a trip are in flight
+// together, which is what the four-segments-per-trip layout was written for
+template <int TY, int THREADS, int DC>
 __global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
 {
+    const int D = DC > 0 ? DC : p.D;
     constexpr int kPerLane = THREADS / 64;   // chunk totals per lane in the scan by wave 0
     using S = Storage<TY>;
     using T = typename S::T;
@@ -116,8 +122,8 @@ __global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
     int n = p.P, q = p.Q;
     if (p.point_counts) n = (int)max(0ll, min((long long)p.P, load_count(p.point_counts, b, p.counts_i64)));
     if (p.dist_counts) q = (int)max(0ll, min((long long)p.Q, load_count(p.dist_counts, b, p.counts_i64)));
-    const T* pts = static_cast<const T*>(p.points) + (size_t)b * p.P * p.D;
-    T* out = p.out_points ? static_cast<T*>(p.out_points) + (size_t)b * p.Q * p.D : nullptr;
+    const T* pts = static_cast<const T*>(p.points) + (size_t)b * p.P * D;
+    T* out = p.out_points ? static_cast<T*>(p.out_points) + (size_t)b * p.Q * D : nullptr;
     const Acc nan = std::numeric_limits<Acc>::quiet_NaN();
 
     // this workgroup's share of the queries: many queries of few polylines are spread over several workgroups (each repeats
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
 
     if (n == 0) {  // undefined polyline: NaN everywhere (polyline_kernels.cuh:216-225)
         if (out)
-            for (int i = q_begin * p.D + t; i < q_stop * p.D; i += THREADS) S::store(out + i, nan);
+            for (int i = q_begin * D + t; i < q_stop * D; i += THREADS) S::store(out + i, nan);
         if (p.out_lengths && t == 0 && first_chunk) S::store(static_cast<T*>(p.out_lengths) + b, nan);
         if (p.out_boxes) {
             const int groups = (p.Q + 63) / 64;
@@ -140,6 +146,11 @@ __global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
     }
 
     Acc* accum = p.use_scratch ? static_cast<Acc*>(p.scratch) + (size_t)b * p.P : reinterpret_cast<Acc*>(lds_raw);
+    // the thread's first query distance does not depend on the scan: requested here, ahead of the four barriers, instead of as a
+    // round trip of its own behind them
+    const T* dist = static_cast<const T*>(p.distances) + (size_t)b * p.Q;
+    Acc first_d = 0;
+    if (out && q_begin + t < q_stop) first_d = S::load(dist + q_begin + t);
 
     // ---- segment lengths, chunked: thread t owns segments [lo, hi), writes the chunk-local inclusive prefix
     const int n_seg = n - 1;
@@ -156,8 +167,8 @@ __global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
         for (int u = 0; u < kBatch; ++u) {
             const int s = min(s0 + u * THREADS, n_seg - 1);      // clamped: loads stay in range, surplus results are dropped
             Acc acc2 = 0;
-            for (int d = 0; d < p.D; ++d) {
-                const Acc diff = S::load(pts + (size_t)s * p.D + d) - S::load(pts + (size_t)(s + 1) * p.D + d);
+            for (int d = 0; d < D; ++d) {
+                const Acc diff = S::load(pts + (size_t)s * D + d) - S::load(pts + (size_t)(s + 1) * D + d);
                 if constexpr (TY == kPF32)
                     acc2 = accv_poly::seg_length2_step(acc2, diff);   // (pinned: the fused lane raster repeats it, polyline_arith.h)
                 else
@@ -215,7 +226,6 @@ __global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
     if (!out) return;
 
     // ---- queries
-    const T* dist = static_cast<const T*>(p.distances) + (size_t)b * p.Q;
     const Acc eps = std::numeric_limits<Acc>::epsilon();
     // (whole waves walk the loop together: when group boxes are wanted, the 64 lanes of a wave hold 64 consecutive samples
     // and reduce their bounding box with shuffles)
@@ -224,12 +234,12 @@ __global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
     for (int i = q_begin + t; i < q_span; i += THREADS) {
         float bx = __builtin_nanf(""), by = bx;  // sample coordinates for the group box (D == 2, f32 instantiation)
         if (i < q_stop) {
-            Acc d = S::load(dist + i);
+            Acc d = i == q_begin + t ? first_d : S::load(dist + i);
             if (p.relative) {
                 if constexpr (TY == kPF32) d = accv_poly::scale_query(d, total);
                 else d *= total;
             }
-            T* res = out + (size_t)i * p.D;
+            T* res = out + (size_t)i * D;
             // last index whose accumulated distance is <= d (polyline_common.cuh:89-116)
             int idx;
             if (accum[0] > d) {
@@ -247,30 +257,72 @@ __global__ __launch_bounds__(THREADS) void polyline_kernel(const PolyParams p)
                 }
                 idx = mn;
             }
+            if constexpr (DC > 0) {
+                // every coordinate is READ before the first one is written: as far as the compiler knows the output may alias the
+                // points, so a write between two reads made every coordinate a round trip of its own
+                const bool inside = idx >= 0 && idx < n - 1;
+                const int ia = inside ? idx : (idx == -1 ? 0 : n - 1);
+                const T* a = pts + (size_t)ia * D;
+                const T* c = inside ? a + D : a;
+                T ra[DC], rc[DC];
+#pragma unroll
+                for (int k = 0; k < DC; ++k) {
+                    ra[k] = a[k];
+                    rc[k] = c[k];
+                }
+                Acc d0 = 0, d1 = 0;
+                if (inside) {
+                    d0 = accum[idx];
+                    d1 = accum[idx + 1];
+                }
+                const Acc len = d1 - d0;
+                if (inside && len >= eps) {
+                    Acc w0, w1;
+                    if constexpr (TY == kPF32) {
+                        accv_poly::lerp_weights(d, d0, d1, len, w0, w1);
+                    } else {
+                        w1 = (d - d0) / len;
+                        w0 = (d1 - d) / len;
+                    }
+#pragma unroll
+                    for (int k = 0; k < DC; ++k) {
+                        if constexpr (TY == kPF32) {
+                            ra[k] = accv_poly::lerp_coord(ra[k], w0, rc[k], w1);
+                            res[k] = ra[k];
+                        } else {
+                            S::store(res + k, S::load(&ra[k]) * w0 + S::load(&rc[k]) * w1);
+                        }
+                    }
+                } else {   // before the first / beyond the last point, or a segment shorter than epsilon: its lower point
+#pragma unroll
+                    for (int k = 0; k < DC; ++k) S::copy(res + k, &ra[k]);
+                }
+                if constexpr (TY == kPF32 && DC == 2) {   // what this thread wrote (group boxes: f32, 2-D only)
+                    bx = ra[0];
+                    by = ra[1];
+                }
+            } else {
             if (idx >= 0 && idx < n - 1) {
                 const Acc d0 = accum[idx], d1 = accum[idx + 1], len = d1 - d0;
-                const T* a = pts + (size_t)idx * p.D;
-                const T* c = a + p.D;
+                const T* a = pts + (size_t)idx * D;
+                const T* c = a + D;
                 if (len >= eps) {
                     if constexpr (TY == kPF32) {
                         float w0, w1;
                         accv_poly::lerp_weights(d, d0, d1, len, w0, w1);
-                        for (int k = 0; k < p.D; ++k) res[k] = accv_poly::lerp_coord(a[k], w0, c[k], w1);
+                        for (int k = 0; k < D; ++k) res[k] = accv_poly::lerp_coord(a[k], w0, c[k], w1);
                     } else {
                         const Acc w1 = (d - d0) / len, w0 = (d1 - d) / len;
-                        for (int k = 0; k < p.D; ++k) S::store(res + k, S::load(a + k) * w0 + S::load(c + k) * w1);
+                        for (int k = 0; k < D; ++k) S::store(res + k, S::load(a + k) * w0 + S::load(c + k) * w1);
                     }
                 } else {
-                    for (int k = 0; k < p.D; ++k) S::copy(res + k, a + k);
+                    for (int k = 0; k < D; ++k) S::copy(res + k, a + k);
                 }
             } else if (idx == -1) {
-                for (int k = 0; k < p.D; ++k) S::copy(res + k, pts + k);
+                for (int k = 0; k < D; ++k) S::copy(res + k, pts + k);
             } else {
-                for (int k = 0; k < p.D; ++k) S::copy(res + k, pts + (size_t)(n - 1) * p.D + k);
+                for (int k = 0; k < D; ++k) S::copy(res + k, pts + (size_t)(n - 1) * D + k);
             }
-            if (p.out_boxes) {  // what this thread just wrote
-                bx = (float)S::load(res);
-                by = (float)S::load(res + 1);
             }
         }
         if (p.out_boxes) {
@@ -367,12 +419,21 @@ int accv_polyline_sample_boxes(const void* points, const void* distances, const 
     if (p.q_chunk < threads) p.q_chunk = (int)threads;
     chunks = std::max<long long>(1, ((long long)max_distances + p.q_chunk - 1) / p.q_chunk);
     const dim3 grid((unsigned)batch, (unsigned)chunks), block((unsigned)threads);
-#define ACCV_LAUNCH_POLY(TYV)                                                                               \
+#define ACCV_LAUNCH_POLY_D(TYV, DCV)                                                                        \
     do {                                                                                                    \
         if (wide)                                                                                           \
-            hipLaunchKernelGGL((polyline_kernel<TYV, 1024>), grid, block, lds, stream, p);                  \
+            hipLaunchKernelGGL((polyline_kernel<TYV, 1024, DCV>), grid, block, lds, stream, p);             \
         else                                                                                                \
-            hipLaunchKernelGGL((polyline_kernel<TYV, kThreads>), grid, block, lds, stream, p);              \
+            hipLaunchKernelGGL((polyline_kernel<TYV, kThreads, DCV>), grid, block, lds, stream, p);         \
+    } while (0)
+#define ACCV_LAUNCH_POLY(TYV)                                                                               \
+    do {                                                                                                    \
+        if (num_dims == 2)                                                                                  \
+            ACCV_LAUNCH_POLY_D(TYV, 2);                                                                     \
+        else if (num_dims == 3)                                                                             \
+            ACCV_LAUNCH_POLY_D(TYV, 3);                                                                     \
+        else                                                                                                \
+            ACCV_LAUNCH_POLY_D(TYV, 0);                                                                     \
     } while (0)
     switch (dtype) {
         case kPF32: ACCV_LAUNCH_POLY(kPF32); break;
@@ -381,6 +442,7 @@ int accv_polyline_sample_boxes(const void* points, const void* distances, const 
         default: ACCV_LAUNCH_POLY(kPBF16); break;
     }
 #undef ACCV_LAUNCH_POLY
+#undef ACCV_LAUNCH_POLY_D
     return accv::check_launch("polyline");
 }
 
