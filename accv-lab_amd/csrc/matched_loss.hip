@@ -49,6 +49,16 @@ __device__ __forceinline__ long long load_int(const void* p, long long i, int is
 {
     return is64 ? static_cast<const long long*>(p)[i] : (long long)static_cast<const int*>(p)[i];
 }
+__device__ __forceinline__ void load_int_pair(const void* p, const void* q, long long i, int is64, long long& a, long long& b)
+{
+    if (is64) {
+        a = static_cast<const long long*>(p)[i];
+        b = static_cast<const long long*>(q)[i];
+    } else {
+        a = static_cast<const int*>(p)[i];
+        b = static_cast<const int*>(q)[i];
+    }
+}
 __device__ __forceinline__ long long wrap_index(long long j, long long width)
 {
     if (j < 0) j += width;   // negative indices wrap once, as in the gather kernels (cu:75-77)
@@ -145,8 +155,10 @@ __global__ __launch_bounds__(256) void matched_reduce_kernel(const MatchedDesc d
     A acc = A(0);
     for (long long t = threadIdx.x; t < total; t += 256) {
         const long long j = t / work, k = t - j * work;
-        const long long ga = wrap_index(load_int(d.idx_a, i * d.idx_stride + j, d.idx_i64), d.w_a);
-        const long long gb = wrap_index(load_int(d.idx_b, i * d.idx_stride + j, d.idx_i64), d.w_b);
+        long long ia, ib;   // both match indices in ONE branch on their dtype: two load_int() calls are two branch diamonds, and
+                            // hipcc waits for the first index before it requests the second (a dependent round trip for nothing)
+        load_int_pair(d.idx_a, d.idx_b, i * d.idx_stride + j, d.idx_i64, ia, ib);
+        const long long ga = wrap_index(ia, d.w_a), gb = wrap_index(ib, d.w_b);
         if (ga < 0 || gb < 0) continue;
         const A w = dw ? to_acc(dw[i * d.w_a + ga]) : A(1);
         if constexpr (KIND == kIoUxyxy) {
@@ -187,8 +199,10 @@ __global__ __launch_bounds__(256) void matched_reduce_bwd_kernel(const MatchedDe
     const A g = grad_out[i];
     for (long long t = threadIdx.x; t < total; t += 256) {
         const long long j = t / work, k = t - j * work;
-        const long long ga = wrap_index(load_int(d.idx_a, i * d.idx_stride + j, d.idx_i64), d.w_a);
-        const long long gb = wrap_index(load_int(d.idx_b, i * d.idx_stride + j, d.idx_i64), d.w_b);
+        long long ia, ib;   // both match indices in ONE branch on their dtype: two load_int() calls are two branch diamonds, and
+                            // hipcc waits for the first index before it requests the second (a dependent round trip for nothing)
+        load_int_pair(d.idx_a, d.idx_b, i * d.idx_stride + j, d.idx_i64, ia, ib);
+        const long long ga = wrap_index(ia, d.w_a), gb = wrap_index(ib, d.w_b);
         if (ga < 0 || gb < 0) continue;
         const A w = dw ? to_acc(dw[i * d.w_a + ga]) : A(1);
         if constexpr (KIND == kIoUxyxy) {
