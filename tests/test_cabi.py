@@ -72,6 +72,39 @@ def test_argument_validation_without_gpu(path):
         nat.check(-1, "unit test")
 
 
+def test_lane_raster_shape_rule_and_rider_argument_checks_without_gpu():
+    """host logic of the round-3 lane entry points: which shapes the one-launch lane raster takes
+    (accv_draw_polylines_fused_applicable) and what the sampler rider refuses — decided before anything touches the device"""
+    from accvlab import _amd_native as nat
+
+    lib = nat.ctypes_lib()
+    one = lambda *v: (ctypes.c_int * len(v))(*v)
+    hs, ws = one(512), one(1024)
+    # 64 point slots per frame: points rounded up to a power of two (>= 4) x polylines
+    for lanes, points, samples, want in ((1, 64, 32, 1), (2, 64, 32, 0), (1, 65, 32, 0), (16, 4, 6, 1), (17, 4, 6, 0), (16, 4, 7, 0),
+                                         (4, 16, 32, 1), (5, 16, 32, 0), (2, 17, 32, 1), (3, 17, 32, 0), (2, 24, 368, 1), (2, 24, 369, 0),
+                                         (0, 24, 32, 0), (2, 0, 32, 0), (2, 24, 0, 0)):
+        assert lib.accv_draw_polylines_fused_applicable(hs, ws, 1, 2, lanes, points, samples) == want, (lanes, points, samples)
+    assert lib.accv_draw_polylines_fused_applicable(None, ws, 1, 2, 1, 24, 32) == 0
+    assert lib.accv_draw_polylines_fused_applicable(hs, ws, 5, 2, 1, 24, 32) == 0               # more than four scales
+    assert lib.accv_draw_polylines_fused_applicable(one(16), one(128), 1, 2, 2, 24, 256) == 0   # coarse tiles in the majority
+    assert lib.accv_draw_polylines_fused_applicable(one(256), one(1024), 1, 2, 2, 24, 256) == 1
+    # the fused entry point refuses shapes outside that rule, the rider polylines the wave-level sampler does not take
+    d = ctypes.c_void_p(64)
+    st = (ctypes.c_float * 1)(1.0)
+    ptrs = (ctypes.c_void_p * 1)(64)
+    assert lib.accv_draw_polylines_multiscale_f32(ptrs, hs, ws, st, 1, 2, d, 5, 64, None, d, 96, 2, 6.0, 1.0, 1, None) == -1
+    assert b"fused" in lib.accv_last_error()
+    assert lib.accv_draw_polylines_multiscale_f32(ptrs, hs, ws, st, 1, 0, d, 5, 64, None, d, 96, 2, 6.0, 1.0, 1, None) == 0     # empty batch
+    rider = lambda points, samples, out: lib.accv_draw_heatmap_multiscale_sample_f32(
+        ptrs, hs, ws, st, 1, 2, None, None, d, 0, 6.0, 1.0, 0, d, 6, points, None, samples, out, d, None)
+    assert rider(65, 64, d) == -1 and b"64 points" in lib.accv_last_error()
+    assert rider(0, 64, d) == -1
+    assert rider(9, 100, d) == -1 and b"multiple of 64" in lib.accv_last_error()
+    assert rider(9, 64, None) == -1 and b"null" in lib.accv_last_error()
+    assert rider(9, 64, ctypes.c_void_p(68)) == -1 and b"alignment" in lib.accv_last_error()
+
+
 @pytest.mark.parametrize("value", [4, 1, 0])
 def test_null_pointer_sweep_is_rejected_or_empty(value):
     """every int-returning entry point called with NULL for every pointer and `value` for every integer: the call must come
