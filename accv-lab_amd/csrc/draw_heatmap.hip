@@ -27,6 +27,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdint>
 #include <cstring>
@@ -1639,6 +1640,22 @@ int launch_splat(SplatParams p, long long planes, bool clear, int sm, hipStream_
     return accv::check_launch("draw_heatmap splat kernel");
 }
 
+// compute units of the current device (cached per device ordinal; 0 when the query fails)
+long long compute_units()
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
+        cached[dev].store(n, std::memory_order_relaxed);
+        v = n;
+    }
+    return v;
+}
+
 int dispatch_splat(SplatParams p, long long planes, bool clear, unsigned flags, hipStream_t stream, const LaunchEvents& ev)
 {
     const bool small_hint = (flags & ACCV_HM_SMALL_RADII) != 0;
@@ -1670,6 +1687,17 @@ int dispatch_splat(SplatParams p, long long planes, bool clear, unsigned flags, 
             rows = 8;
         else
             rows = 8;
+        // ... with one exception (round 3): a fused-clear launch whose 128 x 16 tiles are MORE than the chip holds at once (24
+        // one-wave workgroups per CU) while its 128 x 32 tiles all fit (16 per CU) runs as a single round of resident tiles
+        // instead of one full round plus a short second one — the 8-frame shards of the strong-scaling split (8160 tiles on
+        // 256 CUs): 18.1 / 13.8 -> 17.3 / 13.2 us slowest / fastest shard (profiles/r03_small_launch_tile_rows.log); 16 frames
+        // and more, which need several rounds either way, keep R = 8 (+0.5..1.5 % with 128 x 32 there)
+        if (!(flags & (ACCV_HM_TILE_ROWS_8 | ACCV_HM_TILE_ROWS_16)) && clear && vec4 && !small_hint) {
+            const long long cus = compute_units();
+            const long long tx = (p.W + 127) / 128;
+            const long long tiles8 = planes * tx * ((p.H + 15) / 16), tiles16 = planes * tx * ((p.H + 31) / 32);
+            if (cus > 0 && tiles8 > 24 * cus && tiles16 <= 16 * cus) rows = 16;
+        }
     }
     if (!p.labels) p.labels = p.radii;  // branch-free candidate loads: always a readable array (ignored when cls < 0)
     if (!vec4) return launch_splat<1, 8>(p, planes, clear, 0, stream, ev);

@@ -57,6 +57,20 @@ def main():
         h = ctypes.CDLL(os.path.abspath(path))
         h.accv_draw_heatmap_batched_f32.restype, h.accv_draw_heatmap_batched_f32.argtypes = nat.SIGNATURES["accv_draw_heatmap_batched_f32"]
         alts[os.path.basename(path).replace("libaccv_hip_", "").replace(".so", "")] = h
+    if "--tile-rows" in sys.argv:      # 128 x 16 tiles (default) against 128 x 32 tiles, per shard size of the strong split
+        for frames in (8, 16, 32, 64):
+            row = {}
+            for name, extra in (("128x16 tiles", nat.HM_TILE_ROWS_8), ("128x32 tiles", nat.HM_TILE_ROWS_16)):
+                def one(lo=0, hi=frames, extra=extra):
+                    nat.check(lib.accv_draw_heatmap_batched_f32(hm.data_ptr() + lo * H * W * 4, hi - lo, 0, H, W, c.data_ptr() + lo * nmax * 8,
+                                                                r.data_ptr() + lo * nmax * 4, n.data_ptr() + lo * 8, None, nmax, 6.0, 1.0,
+                                                                flags | extra, stream), "draw")
+                per = []
+                for k in range(B // frames):
+                    per.append(timed(lambda: one(k * frames, (k + 1) * frames), warm=100, iters=200))
+                row[name] = {"slowest_us": round(max(per) * 1e3, 2), "fastest_us": round(min(per) * 1e3, 2)}
+            print(json.dumps({"frames_per_launch": frames, **row}), flush=True)
+        return
     if alts:
         libs = {"shipped": lib, **alts}
         for frames in (8, 16, 32, 64):

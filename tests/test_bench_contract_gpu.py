@@ -35,7 +35,8 @@ def test_bench_line_has_the_contract_fields(monkeypatch):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["kernel"].startswith("splat_kernel<PX=4,R=8,CLEAR=1,SM=0>")
+    # (8 frames: the one-round launch takes 128 x 32 tiles on a 256-CU chip, tests/test_draw_heatmap_gpu.py)
+    assert r["kernel"].startswith(("splat_kernel<PX=4,R=8,CLEAR=1,SM=0>", "splat_kernel<PX=4,R=16,CLEAR=1,SM=0>"))
     assert r["algorithmic_bytes"] == 8 * 1080 * 1920 * 4 + 12 * d["config"]["objects_per_gpu"] + 4 * 8
     assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.02            # kernel time cannot exceed the wall time of a step
@@ -47,7 +48,8 @@ def test_bench_line_has_the_contract_fields(monkeypatch):
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
     assert "inplace" in d["secondary"] and "rule_B" in d["secondary"]
-    assert r["traffic"] is None and "frames per launch" in r["traffic_source"]      # the PMC record is for 64-frame launches
+    # the PMC record is for 64-frame launches of the 128 x 16 instantiation
+    assert r["traffic"] is None and ("frames per launch" in r["traffic_source"] or "this run dispatched" in r["traffic_source"])
     assert r["frac_wall"] <= r["frac_region"] * 1.02 <= r["frac"] * 1.05
     # both scaling modes are in the line: `value` is the weak one, the strong split is predicted from one GPU at N = 1
     sec = d["secondary"]

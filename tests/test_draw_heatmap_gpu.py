@@ -434,6 +434,34 @@ def test_batched_op_is_graph_capturable():
     _close(hm, ref2, "graph replay with new inputs")
 
 
+def test_one_round_launches_take_the_taller_tiles():
+    """a fused-clear launch whose 128 x 16 tiles are more than the chip holds at once while its 128 x 32 tiles all fit (the
+    8-frame shards of the strong-scaling split) runs with the taller tiles — one round of resident tiles; same map either way"""
+    from accvlab import _amd_native as nat
+    from accvlab.draw_heatmap import ops
+
+    _, draw_heatmap_batched = _dh()
+    if ops._FORCED_FLAGS & (nat.HM_TILE_ROWS_8 | nat.HM_TILE_ROWS_16 | nat.HM_SMALL_RADII):
+        pytest.skip("the kernel-variant fixture pins the tile height")
+    cus = torch.cuda.get_device_properties(DEV).multi_processor_count
+    g = torch.Generator().manual_seed(11)
+    for frames, clear, want16 in ((8, True, True), (16, True, False), (8, False, False), (4, True, False)):
+        h, w = 1080, 1920
+        tiles8, tiles16 = frames * 15 * 68, frames * 15 * 34
+        assert want16 == (clear and tiles8 > 24 * cus and tiles16 <= 16 * cus), "the test's table assumes 256 compute units"
+        c = torch.stack([torch.randint(0, w, (frames, 40), generator=g), torch.randint(0, h, (frames, 40), generator=g)], -1).int().to(DEV)
+        r = torch.randint(1, 40, (frames, 40), generator=g).int().to(DEV)
+        n = torch.randint(1, 41, (frames,), generator=g).to(DEV)
+        base = torch.rand(frames, h, w, generator=g).mul_(0.2).to(DEV)
+        got = base.clone()
+        draw_heatmap_batched(got, rb(c, n), rb(r, n), clear=clear)
+        assert ("R=16" in nat.last_dispatch()) == want16, (frames, clear, nat.last_dispatch())
+        ref = base.clone()
+        draw_heatmap_batched(ref, rb(c, n), rb(r, n), clear=clear, tile_rows=8)
+        assert "R=8" in nat.last_dispatch()
+        assert torch.equal(got, ref)
+
+
 def test_dispatch_string_follows_the_public_hints(kernel_variant):
     """accv_draw_heatmap_last_dispatch reports the instantiation that ran (bench.py derives roofline.kernel from it)"""
     from accvlab import _amd_native as nat
