@@ -1,13 +1,8 @@
 #!/bin/bash
-set -uo pipefail
-ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
-OUT="$ROOT/gpurun_out/r03"; mkdir -p "$OUT"
-cd "$ROOT"
-timeout -k 10 600 python -m pytest tests/test_draw_heatmap_gpu.py tests/test_bench_contract_gpu.py tests/test_config_sizes_gpu.py -m gpu -x -q > "$OUT/rows_rule_tests.log" 2>&1; rc=$?; tail -6 "$OUT/rows_rule_tests.log" | cut -c1-300; [ $rc -eq 0 ] || exit 1
-timeout -k 10 300 python bench.py --no-configs > "$OUT/bench_rows_rule.json" 2>/dev/null; python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/r03/bench_rows_rule.json").read().strip().splitlines()[-1])
-print(d["value"], d["roofline"]["frac"])
-p=d["secondary"]["strong_scaling_prediction_from_one_gpu"]["splits"]
-for k,v in p.items(): print(k, v["frames_per_gpu"], round(v["ms_slowest_shard"]*1e3,2), round(v["predicted_speedup"],2))
-PY
+cd "${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p gpurun_out/r03
+ACCV_HIP_LIB=accv-lab_amd/accvlab/_amd_native/libaccv_hip_boxr16.so timeout -k 10 300 python -m pytest tests/test_multiscale_gpu.py tests/test_targets_multiscale_gpu.py -m gpu -x -q 2>&1 | tail -2
+for i in 1 2; do
+for lib in "" accv-lab_amd/accvlab/_amd_native/libaccv_hip_boxr16.so; do
+ACCV_HIP_LIB=$lib timeout -k 10 200 python scripts/bench_configs.py 3 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['secondary']; print('$lib'[-18:] or 'shipped', 'step', round(d['ms_per_step']*1e3,2), 'box', round(s['box_maps_only_ms']*1e3,2), 'lanes', round(s['lane_raster_only_ms']*1e3,2), 'separate', round(s['separate_operators_ms']*1e3,2))"
+done; done
