@@ -441,8 +441,14 @@ def test_one_round_launches_take_the_taller_tiles():
     from accvlab.draw_heatmap import ops
 
     _, draw_heatmap_batched = _dh()
-    if ops._FORCED_FLAGS & (nat.HM_TILE_ROWS_8 | nat.HM_TILE_ROWS_16 | nat.HM_SMALL_RADII):
-        pytest.skip("the kernel-variant fixture pins the tile height")
+    pinned, ops._FORCED_FLAGS = ops._FORCED_FLAGS, 0      # (the kernel-variant fixture pins the tile height: lifted for this test)
+    try:
+        _one_round_rule_cases(nat, draw_heatmap_batched)
+    finally:
+        ops._FORCED_FLAGS = pinned
+
+
+def _one_round_rule_cases(nat, draw_heatmap_batched):
     cus = torch.cuda.get_device_properties(DEV).multi_processor_count
     g = torch.Generator().manual_seed(11)
     for frames, clear, want16 in ((8, True, True), (16, True, False), (8, False, False), (4, True, False)):
