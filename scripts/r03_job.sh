@@ -4,14 +4,5 @@ ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/r03"
 mkdir -p "$OUT"
 cd "$ROOT"
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/gpu_tests_full.log" 2>&1; rc=$?; tail -4 "$OUT/gpu_tests_full.log" | cut -c1-300; [ $rc -eq 0 ] || exit 1
-timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "[r03] smoke rc=$?"; tail -1 "$OUT/smoke.log"
-timeout -k 10 300 python bench.py > "$OUT/bench_final.json" 2> "$OUT/bench_final.err"; echo "[r03] bench rc=$?"
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 > "$OUT/bench_final_k20.json" 2> "$OUT/bench_final_k20.err"; echo "[r03] bench k20 rc=$?"
-python - <<'PY'
-import json
-for f in ("bench_final","bench_final_k20"):
-    d=json.loads(open(f"gpurun_out/r03/{f}.json").read().strip().splitlines()[-1])
-    c3=d["secondary"]["configs"]["configs[3]"]
-    print(f, round(d["value"]), round(d["roofline"]["frac"],3), round(d["roofline"].get("frac_wall"),3), {k:round(v.get("value"),1) for k,v in d["secondary"]["configs"].items()}, "c3 lanes-only us", round(c3["secondary"]["lane_raster_only_ms"]*1e3,2), "separate", round(c3["secondary"]["separate_operators_ms"]*1e3,2), "step", round(c3["ms_per_step"]*1e3,2))
-PY
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/gpu_tests_full.log" 2>&1; rc=$?; tail -3 "$OUT/gpu_tests_full.log" | cut -c1-300; [ $rc -eq 0 ] || exit 1
+ACCV_FUZZ_SCALE=10 timeout -k 10 1000 python -m pytest tests/test_fuzz_gpu.py -m gpu -x -q > "$OUT/fuzz_soak_final.log" 2>&1; echo "[r03] soak rc=$?"; tail -3 "$OUT/fuzz_soak_final.log" | cut -c1-300
