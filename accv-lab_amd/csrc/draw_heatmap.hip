@@ -17,6 +17,9 @@
 //   splat_multi_kernel  the same body over the tiles of up to four scales in one launch, objects given as float
 //                       centres / boxes and converted per scale inside the cull (SRC=1)
 //   splat_small_kernel  point-like objects (ACCV_HM_SMALL_RADII): tile in LDS, lanes walk each hit's box, ds_max_f32
+//   splat_points_multi_kernel   lane raster: sampled polyline points of all scales, two-level cull (group boxes), same LDS tile
+//   lane_raster_multi_kernel    lane raster of sparse lane sets in ONE launch: the tile waves sample the polylines themselves
+//   splat_multi_sampler_kernel  splat_multi_kernel with the polyline sampler riding in the launch (draw_targets_multiscale)
 //   bin_* kernels       flat API: counting sort of the objects by plane into plane-sorted copies
 //   targets_from_*      float boxes / sampled polyline points -> integer centre + radius
 //
