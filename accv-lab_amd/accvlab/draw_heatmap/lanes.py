@@ -257,34 +257,31 @@ def draw_targets_multiscale(heatmaps, centers, bboxes, out_size_factors, lane_he
     kernel, also take the rider here: 32.3 against 33.9 us per step on config 3's maps with one polyline per frame.)"""
     heatmaps, lane_heatmaps = list(heatmaps), list(lane_heatmaps)
     lane_strides = [float(f) for f in (out_size_factors if lane_out_size_factors is None else lane_out_size_factors)]
-    ok = isinstance(polylines, torch.Tensor) and polylines.is_cuda and polylines.dim() == 4 and polylines.size(3) == 2 and \
-        polylines.dtype == torch.float32 and polylines.size(0) * polylines.size(1) > 0 and polylines.size(2) <= 64 and \
-        num_samples % 64 == 0 and 64 <= num_samples <= (1 << 20) and 1 <= len(lane_heatmaps) <= 4 and radius >= 0 and \
+    shape = polylines.shape if isinstance(polylines, torch.Tensor) else ()
+    ok = len(shape) == 4 and shape[3] == 2 and polylines.is_cuda and polylines.dtype == torch.float32 and \
+        shape[0] * shape[1] > 0 and shape[2] <= 64 and num_samples % 64 == 0 and 64 <= num_samples <= (1 << 20) and radius >= 0 and \
         len(lane_heatmaps) == len(lane_strides)
-    for hm in lane_heatmaps:
-        ok = ok and isinstance(hm, torch.Tensor) and hm.is_cuda and hm.dim() == 3 and hm.is_contiguous() and \
-            hm.dtype == torch.float32 and hm.size(0) == polylines.size(0) and hm.device == polylines.device and \
-            hm.size(2) % 4 == 0 and hm.data_ptr() % 16 == 0 and hm.size(1) * hm.size(2) * 4 < (1 << 31)
-    if ok:
-        k = len(lane_heatmaps)
-        hs = (ctypes.c_int * k)(*[hm.size(1) for hm in lane_heatmaps])
-        ws_ = (ctypes.c_int * k)(*[hm.size(2) for hm in lane_heatmaps])
-        ok = TARGETS_PREFER_RIDER or not _fused_applies(_nat.lib(), hs, ws_, k, polylines, num_samples)
+    # every map is looked at ONCE here and the arrays are handed on (the two operators below would each walk them again: the
+    # python side of a step was 31 us against 38 us of kernels)
+    lane_geo = _ops._quick_geometry(lane_heatmaps, shape[0], polylines.device) if ok else None
+    box_geo = _ops._quick_geometry(heatmaps, shape[0], polylines.device) if lane_geo is not None else None
+    ok = box_geo is not None
+    if ok and not TARGETS_PREFER_RIDER:
+        ok = not _fused_applies(_nat.lib(), lane_geo[1], lane_geo[2], len(lane_heatmaps), polylines, num_samples)
     if not ok:
         _ops.draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diameter_to_sigma_factor, k_scale, clear=clear)
         draw_polylines_multiscale(lane_heatmaps, polylines, num_samples, radius, lane_strides, diameter_to_sigma_factor, k_scale,
                                   num_points=num_points, num_lanes=num_lanes, clear=clear)
         return
-    b, l = polylines.shape[:2]
+    b, l = shape[0], shape[1]
     dev = polylines.device
-    with _nat.device_guard(dev):
-        nbytes = _nat.lib().accv_draw_points_workspace_bytes(b, l * num_samples)
-        work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    nbytes = _nat.lib().accv_draw_points_workspace_bytes(b, l * num_samples)      # (host arithmetic: no device guard needed)
+    work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     job = _SamplerJob(polylines, num_points, num_samples, work)
     _ops.draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diameter_to_sigma_factor, k_scale, clear=clear,
-                                 _sampler_job=job)
+                                 _sampler_job=job, _geometry=box_geo)
     draw_polylines_multiscale(lane_heatmaps, polylines, num_samples, radius, lane_strides, diameter_to_sigma_factor, k_scale,
-                              num_points=num_points, num_lanes=num_lanes, clear=clear, _presampled=(job.samples, work))
+                              num_points=num_points, num_lanes=num_lanes, clear=clear, _presampled=(job.samples, work, lane_geo))
 
 
 def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: int, radius: int, out_size_factors,
@@ -302,7 +299,10 @@ def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: in
         raise RuntimeError("heatmaps and out_size_factors must have the same, non-zero length")
     b, l = polylines.shape[:2] if polylines.dim() == 4 else (0, 0)
     fusable = len(heatmaps) <= 4 and radius >= 0
-    for hm in heatmaps:
+    geometry = _presampled[2] if _presampled is not None and len(_presampled) > 2 else None   # maps checked by draw_targets_multiscale
+    if geometry is None and polylines.dim() == 4:
+        geometry = _ops._quick_geometry(heatmaps, b, polylines.device)    # one pass when all is well; else the checks below say why
+    for hm in (heatmaps if geometry is None else ()):
         if not (isinstance(hm, torch.Tensor) and hm.is_cuda and hm.is_contiguous() and hm.dtype == torch.float32):
             raise RuntimeError("every heatmap must be a contiguous float32 CUDA tensor")
         if not (hm.dim() == 3 and hm.size(0) == b and hm.device == polylines.device):
@@ -317,21 +317,23 @@ def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: in
     dev = polylines.device
     lib = _nat.lib()
     k = len(heatmaps)
-    hs = (ctypes.c_int * k)(*[hm.size(1) for hm in heatmaps])
-    ws_ = (ctypes.c_int * k)(*[hm.size(2) for hm in heatmaps])
+    if geometry is None:
+        hs = (ctypes.c_int * k)(*[hm.size(1) for hm in heatmaps])
+        ws_ = (ctypes.c_int * k)(*[hm.size(2) for hm in heatmaps])
+    else:
+        hs, ws_ = geometry[1], geometry[2]
     if _presampled is None and _fused_applies(lib, hs, ws_, k, polylines, num_samples):
         # ONE launch: the tile waves sample the polylines themselves (no sampler launch, no sample buffer)
         _draw_polylines_fused(heatmaps, hs, ws_, strides, polylines, num_samples, radius, diameter_to_sigma_factor, k_scale,
                               num_points, num_lanes, clear)
         return
     if _presampled is not None:   # (draw_targets_multiscale) samples and group boxes were written by the box-map launch
-        samples, work = _presampled
+        samples, work = _presampled[0], _presampled[1]
         nbytes = work.numel()
         boxes_by_sampler = True
     else:
-        with _nat.device_guard(dev):
-            nbytes = lib.accv_draw_points_workspace_bytes(b, n)
-            work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        nbytes = lib.accv_draw_points_workspace_bytes(b, n)      # (host arithmetic; the allocation names its device)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         # the sampler writes the group boxes itself when the groups of 64 do not straddle lanes (one launch less)
         boxes_by_sampler = num_samples % 64 == 0 and b * l > 0
         samples = sample_lanes(polylines, num_samples, num_points=num_points,
@@ -344,7 +346,7 @@ def draw_polylines_multiscale(heatmaps, polylines: torch.Tensor, num_samples: in
         sizes = num_lanes.clamp(0, l) * num_samples
         if sizes.dtype not in (torch.int32, torch.int64):
             sizes = sizes.to(torch.int64)
-    ptrs = (ctypes.c_void_p * k)(*[hm.data_ptr() for hm in heatmaps])
+    ptrs = geometry[0] if geometry is not None else (ctypes.c_void_p * k)(*[hm.data_ptr() for hm in heatmaps])
     st = (ctypes.c_float * k)(*strides)
     flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if sizes.dtype == torch.int64 else 0) | \
         (_nat.HM_GROUP_BOXES_GIVEN if boxes_by_sampler else 0) | _ops._FORCED_FLAGS

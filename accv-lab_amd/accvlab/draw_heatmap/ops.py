@@ -48,6 +48,30 @@ def _hint_flags(clear: bool, small_radii: bool, write_through: bool, tile_rows) 
         (_nat.HM_TILE_ROWS_16 if tile_rows == 16 else _nat.HM_TILE_ROWS_8 if tile_rows == 8 else 0) | _FORCED_FLAGS
 
 
+def _quick_geometry(maps, batch: int, device):
+    """``(ptrs, heights, widths)`` as ctypes arrays when every map is a contiguous float32 ``[batch, H, W]`` CUDA tensor on
+    ``device`` that the one-launch multi-scale kernels take (width a multiple of 4, 16-byte aligned, planes below 2 GiB), else
+    ``None`` — one pass over the maps for callers that hand the arrays on (draw_targets_multiscale)."""
+    k = len(maps)
+    if not 1 <= k <= 4:
+        return None
+    ptrs, hs, ws = [], [], []
+    for hm in maps:
+        if not (isinstance(hm, torch.Tensor) and hm.is_cuda and hm.dtype == torch.float32 and hm.is_contiguous() and
+                hm.device == device):
+            return None
+        shape = hm.shape
+        if len(shape) != 3 or shape[0] != batch:
+            return None
+        ptr = hm.data_ptr()
+        if shape[2] % 4 or ptr % 16 or shape[1] * shape[2] * 4 >= (1 << 31):
+            return None
+        ptrs.append(ptr)
+        hs.append(shape[1])
+        ws.append(shape[2])
+    return (ctypes.c_void_p * k)(*ptrs), (ctypes.c_int * k)(*hs), (ctypes.c_int * k)(*ws)
+
+
 def _require(cond: bool, msg: str) -> None:
     if not cond:
         raise RuntimeError(msg)
@@ -327,7 +351,7 @@ def get_centers_and_radii(centers, bboxes, out_size_factor: float):
 
 
 def draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diameter_to_sigma_factor: float = 6.0,
-                            k_scale: float = 1.0, *, clear: bool = False, _sampler_job=None) -> None:
+                            k_scale: float = 1.0, *, clear: bool = False, _sampler_job=None, _geometry=None) -> None:
     """(extension) Rasterise one batch of objects at several strides.  Equivalent to, for every scale ``s``::
 
         c, r = get_centers_and_radii(centers, bboxes, out_size_factors[s])
@@ -364,7 +388,11 @@ def draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diamete
     if not (counts.dim() == 1 and counts.size(0) == batch):
         raise RuntimeError("nums_targets must be of shape [batch_size]")
     fusable = len(heatmaps) <= 4
-    for hm in heatmaps:
+    if _geometry is None:
+        _geometry = _quick_geometry(heatmaps, batch, c_t.device)    # one pass when all is well; else the checks below say why
+    if _geometry is not None:
+        _same_device(c_t, ("bboxes", b_t), ("nums_targets", counts))     # (the maps are on the centres' device)
+    for hm in (heatmaps if _geometry is None else ()):     # (_geometry given: draw_targets_multiscale has checked the maps already)
         _check_input(hm, "heatmap")
         _check_dtype(hm, torch.float32, "heatmap")
         if not (hm.dim() == 3 and hm.size(0) == batch):
@@ -379,9 +407,12 @@ def draw_heatmap_multiscale(heatmaps, centers, bboxes, out_size_factors, diamete
             _sampler_job.run_separately()
         return
     n = len(heatmaps)
-    ptrs = (ctypes.c_void_p * n)(*[hm.data_ptr() for hm in heatmaps])
-    hs = (ctypes.c_int * n)(*[hm.size(1) for hm in heatmaps])
-    ws = (ctypes.c_int * n)(*[hm.size(2) for hm in heatmaps])
+    if _geometry is None:
+        ptrs = (ctypes.c_void_p * n)(*[hm.data_ptr() for hm in heatmaps])
+        hs = (ctypes.c_int * n)(*[hm.size(1) for hm in heatmaps])
+        ws = (ctypes.c_int * n)(*[hm.size(2) for hm in heatmaps])
+    else:
+        ptrs, hs, ws = _geometry
     st = (ctypes.c_float * n)(*strides)
     flags = (_nat.HM_CLEAR if clear else 0) | (_nat.HM_COUNTS_I64 if counts.dtype == torch.int64 else 0) | _FORCED_FLAGS
     dev = heatmaps[0].device
