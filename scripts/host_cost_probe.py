@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Host (python + binding) cost per call of the multi-scale operators of configs[3]: the same calls on tiny maps, where the GPU work is
+negligible and the loop time is what the host needs to issue a step."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "accv-lab_amd")]
