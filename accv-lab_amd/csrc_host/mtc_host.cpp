@@ -30,6 +30,20 @@ struct Op {
     int64_t arg;  // containers: number of children; leaf: leaf index; pass: index into objects
 };
 
+// One input leaf.  A leaf that came from python is held through its python object (Py_INCREF / Py_DECREF: a few
+// nanoseconds) and read in place: a C++ copy of the tensor handle moves the TensorImpl's reference count between 1 and 2,
+// and each such transition calls into the interpreter to pin / unpin the python object (c10/util/intrusive_ptr.h, "PyObject
+// preservation") — 10 000 leaves: 0.15 ms to take the copies and 1.5 ms to drop them with the Tree.  Leaves made in C++
+// (from_spec / views_on) have no python object yet and are held as tensors.
+struct LeafRef {
+    py::object obj;
+    at::Tensor owned;
+    LeafRef() = default;
+    explicit LeafRef(py::object o) : obj(std::move(o)) {}
+    explicit LeafRef(at::Tensor t) : owned(std::move(t)) {}
+    const at::Tensor& get() const { return obj ? THPVariable_Unpack(obj.ptr()) : owned; }
+};
+
 class Tree {
 public:
     explicit Tree(const py::object& data)
@@ -82,7 +96,7 @@ public:
         return t;
     }
 
-    void set_leaf(int64_t i, const at::Tensor& t) { leaves_.at((size_t)i) = t; }
+    void set_leaf(int64_t i, const at::Tensor& t) { leaves_.at((size_t)i) = LeafRef(t); }
 
     // (scalar type int8[k], ndim int8[k], sizes int64[sum ndim]) of the given (contiguous) leaves
     py::tuple leaf_meta(const py::array_t<int64_t>& idx) const
@@ -93,7 +107,7 @@ public:
         auto n = ndims.mutable_unchecked<1>();
         std::vector<int64_t> sizes;
         for (py::ssize_t k = 0; k < ix.shape(0); ++k) {
-            const at::Tensor& t = leaves_.at((size_t)ix(k));
+            const at::Tensor& t = leaves_.at((size_t)ix(k)).get();
             TORCH_CHECK(t.dim() < 128, "too many dimensions");
             d(k) = (int8_t)t.scalar_type();
             n(k) = (int8_t)t.dim();
@@ -121,6 +135,8 @@ public:
         // the views of a PackedBatch that went to the GPU are outputs like those of make_packed_views: recycled (see there);
         // the CPU unpack (as_leaves) hands its views to the caller as the batch's leaves and keeps out of the pool
         const bool pool_this = !as_leaves && recycling_enabled() && storage_bytes <= kRecycleMaxBytes;
+        if (pool_this) drop_kept_trees();   // (whole trees are kept by make_packed_views only)
+        views_made_ = true;
         std::vector<at::Tensor> next;
         if (pool_this) next.reserve((size_t)ix.shape(0));
         py::ssize_t cursor = 0;
@@ -157,13 +173,13 @@ public:
             const size_t li = (size_t)ix(k);
             if (pool_this) next.push_back(view);
             outs_.at(li) = view;
-            if (as_leaves) leaves_.at(li) = view;
+            if (as_leaves) leaves_.at(li) = LeafRef(view);
         }
         if (pool_this) keep_for_recycling(std::move(next));
     }
 
     int64_t num_leaves() const { return (int64_t)leaves_.size(); }
-    at::Tensor leaf(int64_t i) const { return leaves_.at((size_t)i); }
+    at::Tensor leaf(int64_t i) const { return leaves_.at((size_t)i).get(); }
     void set_out(int64_t i, const at::Tensor& t) { outs_.at((size_t)i) = t; }
 
     // (route int8[n], nbytes int64[n], elem_size int32[n], data_ptr uint64[n], device_index int32[n])
@@ -182,7 +198,7 @@ public:
         auto p = ptr.mutable_unchecked<1>();
         auto d = dev.mutable_unchecked<1>();
         for (int64_t i = 0; i < n; ++i) {
-            const at::Tensor& t = leaves_[(size_t)i];
+            const at::Tensor& t = leaves_[(size_t)i].get();
             if (!t.defined()) {  // packed leaf of a PackedBatch: lives in the batch buffer, produced by views_on
                 r(i) = kExternal;
                 b(i) = 0;
@@ -231,8 +247,36 @@ public:
     // two generations: the views of the last call and of the call before it — a loop of the form
     // `batch = start_copy(next).get()` still holds the previous result while the next one is being built, so the tensors
     // that are free to be re-pointed are those of the call BEFORE the previous one
+    // A generation = the packed views of one call and, when that call's result consisted of nothing else, the result TREE itself
+    // (containers included) with the structure it was built from.  Round 3, second step: the other half of a many-leaf copy is
+    // the life cycle of its CONTAINERS — building 12 k lists / dicts and freeing those of the previous result (1.3 of 2.4 ms for
+    // 10 000 leaves).  When the next call has the same structure (same op list, the very same key / pass-through objects) and
+    // the kept tree is held by nobody but this pool (every container referenced once — by its parent, the root by the pool —
+    // and every leaf by its container slot and the pool only), the tree is handed out AGAIN: its tensors are re-pointed in
+    // place, no container is built or freed.  Anything else — the caller still holds the tree or a part of it, replaced an
+    // element, attached something to a tensor, the structure differs — drops the kept tree (its containers die with the
+    // pool's reference) and falls back to recycling tensor by tensor.
+    struct Generation {
+        uint64_t id = 0;
+        std::vector<at::Tensor> views;
+        py::object root;                    // empty: no kept tree
+        std::vector<Op> ops;
+        std::vector<py::object> objects;
+        void drop_root()
+        {
+            root = py::object();
+            ops.clear();
+            objects.clear();
+        }
+        void clear()
+        {
+            drop_root();
+            std::vector<at::Tensor>().swap(views);
+        }
+    };
     struct Pool {
-        std::vector<at::Tensor> gen[2];
+        Generation gen[2];
+        uint64_t next_id = 1;
     };
     static Pool& recycled()
     {
@@ -275,21 +319,90 @@ public:
         if (!recycling_enabled()) return at::Tensor();
         Pool& pool = recycled();
         for (int g = 1; g >= 0; --g) {
-            if (k >= pool.gen[g].size()) continue;
-            at::Tensor& old = pool.gen[g][k];
+            if (pool.gen[g].root || k >= pool.gen[g].views.size()) continue;   // (a kept tree is taken whole or not at all)
+            at::Tensor& old = pool.gen[g].views[k];
             if (old.defined() && nobody_else_holds(old) && old.dtype() == dtype && old.key_set() == chunk.key_set() &&
                 old.device() == chunk.device())
                 return std::move(old);
         }
         return at::Tensor();
     }
-    // the views of THIS call become the younger generation; what is left of the older one is released
-    static void keep_for_recycling(std::vector<at::Tensor>&& views)
+    // the views of THIS call become the younger generation; what is left of the older one is released.  Returns its id.
+    static uint64_t keep_for_recycling(std::vector<at::Tensor>&& views)
+    {
+        Generation fresh;
+        fresh.views = std::move(views);
+        return keep_generation(std::move(fresh));
+    }
+    static uint64_t keep_generation(Generation&& g)
     {
         Pool& pool = recycled();
-        pool.gen[1].swap(pool.gen[0]);
-        pool.gen[0].swap(views);
-        std::vector<at::Tensor>().swap(views);
+        g.id = pool.next_id++;
+        const uint64_t id = g.id;
+        pool.gen[1] = std::move(pool.gen[0]);
+        pool.gen[0] = std::move(g);
+        return id;
+    }
+    // kept trees are resolved before a call touches the pool tensor by tensor: none may stay behind half used
+    static void drop_kept_trees()
+    {
+        for (auto& g : recycled().gen) g.drop_root();
+    }
+
+    // ---- is the kept tree of `g` free, and does it have this call's structure?
+    static bool leaf_is_free(PyObject* obj, const at::Tensor& view)
+    {
+        if (!THPVariable_Check(obj)) return false;
+        at::TensorImpl* impl = view.unsafeGetTensorImpl();
+        if (THPVariable_Unpack(obj).unsafeGetTensorImpl() != impl) return false;      // the slot was reassigned
+        if (impl->autograd_meta() != nullptr || impl->has_named_tensor_meta()) return false;
+        // C++: the pool's reference + the one the python object owns.  Python: the reference the TensorImpl keeps on its python
+        // object while other C++ references exist (c10/util/intrusive_ptr.h, "PyObject preservation") + the container slot.
+        if (!(view.use_count() == 2 && Py_REFCNT(obj) == 2)) return false;
+        PyObject** dict = _PyObject_GetDictPtr(obj);
+        return dict == nullptr || *dict == nullptr || PyDict_Size(*dict) == 0;
+    }
+    static bool tree_is_free(PyObject* obj, const Generation& g, size_t& cursor, size_t& obj_cursor)
+    {
+        if (cursor >= g.ops.size()) return false;
+        const Op op = g.ops[cursor++];
+        switch (op.kind) {
+            case kLeaf:
+                return (size_t)op.arg < g.views.size() && leaf_is_free(obj, g.views[(size_t)op.arg]);
+            case kPass:
+                return obj_cursor < g.objects.size() && obj == g.objects[obj_cursor++].ptr();
+            case kList: {
+                if (!(PyList_CheckExact(obj) && Py_REFCNT(obj) == 1 && PyList_GET_SIZE(obj) == (Py_ssize_t)op.arg)) return false;
+                for (Py_ssize_t i = 0; i < (Py_ssize_t)op.arg; ++i)
+                    if (!tree_is_free(PyList_GET_ITEM(obj, i), g, cursor, obj_cursor)) return false;
+                return true;
+            }
+            case kTuple: {
+                if (!(PyTuple_CheckExact(obj) && Py_REFCNT(obj) == 1 && PyTuple_GET_SIZE(obj) == (Py_ssize_t)op.arg)) return false;
+                for (Py_ssize_t i = 0; i < (Py_ssize_t)op.arg; ++i)
+                    if (!tree_is_free(PyTuple_GET_ITEM(obj, i), g, cursor, obj_cursor)) return false;
+                return true;
+            }
+            default: {
+                if (!(PyDict_CheckExact(obj) && Py_REFCNT(obj) == 1 && PyDict_Size(obj) == (Py_ssize_t)op.arg)) return false;
+                PyObject *key, *value;
+                Py_ssize_t pos = 0;
+                while (PyDict_Next(obj, &pos, &key, &value)) {
+                    if (!(obj_cursor < g.objects.size() && key == g.objects[obj_cursor++].ptr())) return false;
+                    if (!tree_is_free(value, g, cursor, obj_cursor)) return false;
+                }
+                return true;
+            }
+        }
+    }
+    bool same_structure(const Generation& g) const
+    {
+        if (g.ops.size() != ops_.size() || g.objects.size() != objects_.size()) return false;
+        for (size_t i = 0; i < ops_.size(); ++i)
+            if (g.ops[i].kind != ops_[i].kind || g.ops[i].arg != ops_[i].arg) return false;
+        for (size_t i = 0; i < objects_.size(); ++i)
+            if (g.objects[i].ptr() != objects_[i].ptr()) return false;
+        return true;
     }
 
     void make_packed_views(const py::array_t<int64_t>& idx, const py::array_t<int64_t>& chunk_of,
@@ -303,15 +416,47 @@ public:
         int64_t chunk_bytes = 0;
         for (const auto& c : chunks) chunk_bytes += (int64_t)c.storage().nbytes();
         const bool pool_this = recycling_enabled() && chunk_bytes <= kRecycleMaxBytes;
+        // all leaves of the tree are packed views of this one call (in leaf order): the result tree can be kept / taken whole
+        bool whole = pool_this && !views_made_ && (size_t)ix.shape(0) == leaves_.size();
+        for (py::ssize_t k = 0; whole && k < ix.shape(0); ++k) whole = ix(k) == k;
+        views_made_ = true;
+        int take = -1;   // generation whose kept tree this call takes whole
+        if (pool_this) {
+            Pool& pool = recycled();
+            for (int g = 1; g >= 0 && take < 0; --g) {
+                Generation& gen = pool.gen[g];
+                if (!gen.root) continue;
+                bool fits = whole && gen.views.size() == leaves_.size() && same_structure(gen);
+                for (py::ssize_t k = 0; fits && k < ix.shape(0); ++k) {
+                    const at::Tensor& old = gen.views[(size_t)k];
+                    const at::Tensor& chunk = chunks.at((size_t)ck(k));
+                    fits = old.defined() && old.dtype() == leaves_[(size_t)k].get().dtype() && old.key_set() == chunk.key_set() &&
+                           old.device() == chunk.device();
+                }
+                if (!fits) {   // another structure: the kept tree gives way to tensor-by-tensor recycling of its views
+                    gen.drop_root();
+                    continue;
+                }
+                // the same structure, but somebody still holds (part of) the tree — normally the caller's variable of the
+                // previous step: left alone, it is free one call later
+                size_t cursor = 0, obj_cursor = 0;
+                if (tree_is_free(gen.root.ptr(), gen, cursor, obj_cursor) && cursor == gen.ops.size()) take = g;
+            }
+        }
+        Generation taken;
+        if (take >= 0) {
+            taken = std::move(recycled().gen[take]);
+            recycled().gen[take] = Generation();
+        }
         std::vector<at::Tensor> next;
-        if (pool_this) next.reserve((size_t)ix.shape(0));
+        if (pool_this && take < 0) next.reserve((size_t)ix.shape(0));
         for (py::ssize_t k = 0; k < ix.shape(0); ++k) {
-            const at::Tensor& t = leaves_.at((size_t)ix(k));
+            const at::Tensor& t = leaves_.at((size_t)ix(k)).get();
             const at::Tensor& chunk = chunks.at((size_t)ck(k));
             const int64_t es = (int64_t)t.element_size();
             const int64_t byte_off = chunk.storage_offset() + bs(ck(k)) + of(k);
             TORCH_CHECK(byte_off % es == 0, "packed offset ", byte_off, " is not a multiple of the element size ", es);
-            at::Tensor view = take_recycled((size_t)k, t.dtype(), chunk);
+            at::Tensor view = take >= 0 ? taken.views[(size_t)k] : take_recycled((size_t)k, t.dtype(), chunk);
             if (view.defined()) {   // nobody else holds it: re-point it
                 at::TensorImpl* impl = view.unsafeGetTensorImpl();
                 impl->set_storage_keep_dtype(c10::Storage(chunk.storage()));
@@ -325,16 +470,37 @@ public:
                 impl->set_storage_offset(byte_off / es);
                 view = at::Tensor(std::move(impl));
             }
-            if (pool_this) next.push_back(view);
+            if (pool_this && take < 0) next.push_back(view);
             outs_[(size_t)ix(k)] = std::move(view);
         }
-        keep_for_recycling(std::move(next));
+        if (take >= 0) {   // the kept tree goes out again (rebuild()): this object holds it until then, the pool keeps it as well
+            reused_root_ = taken.root;
+            generation_ = keep_generation(std::move(taken));
+        } else {
+            generation_ = keep_for_recycling(std::move(next));
+            keep_tree_ = whole;
+        }
     }
 
-    py::object rebuild() const
+    py::object rebuild()
     {
+        if (reused_root_) {   // the kept tree, its tensors re-pointed by make_packed_views
+            py::object out = std::move(reused_root_);
+            reused_root_ = py::object();
+            return out;
+        }
         size_t cursor = 0;
-        return build(cursor);
+        py::object out = build(cursor);
+        if (keep_tree_) {   // all leaves are pooled views of one call: keep the tree beside them, if they are still in the pool
+            keep_tree_ = false;
+            for (auto& g : recycled().gen)
+                if (g.id == generation_ && g.id != 0 && g.views.size() == leaves_.size()) {
+                    g.root = out;
+                    g.ops = ops_;
+                    g.objects = objects_;
+                }
+        }
+        return out;
     }
 
 private:
@@ -343,7 +509,7 @@ private:
         PyObject* raw = obj.ptr();
         if (THPVariable_Check(raw)) {
             ops_.push_back({kLeaf, (int64_t)leaves_.size()});
-            leaves_.push_back(THPVariable_Unpack(raw));
+            leaves_.emplace_back(py::reinterpret_borrow<py::object>(obj));
         } else if (PyList_CheckExact(raw)) {
             const py::ssize_t n = PyList_GET_SIZE(raw);
             ops_.push_back({kList, (int64_t)n});
@@ -368,7 +534,7 @@ private:
                 ten = from_numpy_(py::module_::import("numpy").attr("array")(obj, py::arg("order") = "C"));
             }
             ops_.push_back({kLeaf, (int64_t)leaves_.size()});
-            leaves_.push_back(THPVariable_Unpack(ten.ptr()));
+            leaves_.emplace_back(std::move(ten));
         } else {
             ops_.push_back({kPass, (int64_t)objects_.size()});
             objects_.push_back(py::reinterpret_borrow<py::object>(obj));
@@ -414,10 +580,15 @@ private:
     }
 
     std::vector<Op> ops_;
-    std::vector<at::Tensor> leaves_;
+    std::vector<LeafRef> leaves_;
     std::vector<at::Tensor> outs_;
     std::vector<py::object> objects_;  // dict keys and passthrough leaves, in traversal order
     py::object from_numpy_, ndarray_type_;
+    // output recycling: the generation this tree's packed views went into, whether its result tree is to be kept beside them,
+    // and a kept tree that is handed out again
+    uint64_t generation_ = 0;
+    bool keep_tree_ = false, views_made_ = false;
+    py::object reused_root_;
 };
 
 }  // namespace
@@ -439,13 +610,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         .def("views_on", &Tree::views_on)
         .def("rebuild", &Tree::rebuild);
     m.def("release_recycled_outputs", [] {
-              for (auto& g : Tree::recycled().gen) std::vector<at::Tensor>().swap(g);
+              for (auto& g : Tree::recycled().gen) g.clear();
           },
           "drop the output tensors of the last packed copy that are kept for re-use (and the chunk storage they pin)");
     m.def("set_output_recycling", [](bool on) {
         Tree::recycling_enabled() = on && Tree::kRecyclingSupported;
         if (!on)
-            for (auto& g : Tree::recycled().gen) std::vector<at::Tensor>().swap(g);
+            for (auto& g : Tree::recycled().gen) g.clear();
     });
-    m.def("recycled_output_count", [] { return (int64_t)(Tree::recycled().gen[0].size() + Tree::recycled().gen[1].size()); });
+    m.def("recycled_output_count", [] { return (int64_t)(Tree::recycled().gen[0].views.size() + Tree::recycled().gen[1].views.size()); });
+    m.def("recycled_tree_count", [] { return (int64_t)((bool)Tree::recycled().gen[0].root + (bool)Tree::recycled().gen[1].root); },
+          "how many whole result trees (containers included) are kept for re-use");
 }

@@ -352,3 +352,118 @@ def test_repeated_copies_recycle_output_objects_without_touching_held_ones(backg
         assert copier._host.recycled_output_count() > 0
     release_cached_outputs()
     assert copier._host.recycled_output_count() == 0
+
+
+@pytest.mark.parametrize("background", [False, True])
+def test_whole_result_trees_are_handed_out_again_only_when_nobody_holds_them(background):
+    """round 3, second step of output recycling: a result whose leaves are all packed views is kept with its CONTAINERS, and a
+    later copy of the same structure hands the very same tree out again (tensors re-pointed in place) — but only when nobody
+    holds the tree, any of its containers or leaves, nothing was replaced in it or attached to a tensor, and the key /
+    pass-through objects are the same; every result must carry its own call's values whatever happened to the earlier ones"""
+    from accvlab.multi_tensor_copier import copier, release_cached_outputs, set_output_recycling, start_copy
+
+    if copier._host is None or not hasattr(copier._host, "recycled_tree_count"):
+        pytest.skip("host extension not built")
+    import os
+    twin = os.environ.get("ACCV_MTC_PY_HOST") == "1"     # the python twin of the host path builds fresh objects every time:
+    kept_trees = (lambda: 0) if twin else copier._host.recycled_tree_count      # same values, no identities to check
+    release_cached_outputs()
+    tag = object()        # one pass-through object for all calls (tuples are containers: rebuilt, not passed through)
+
+    def batch(k, n=6):
+        return {"gt": [torch.full((3 + i, 4), float(10 * k + i)) for i in range(n)],
+                "ids": (torch.full((5,), 100 * k, dtype=torch.int64), torch.full((2, 2), k, dtype=torch.int32)), "tag": tag,
+                "nested": [{"a": torch.full((2,), float(k))}, [torch.full((1,), float(-k))]]}
+
+    def check(res, k, n=6):
+        assert res["tag"] is tag
+        for i in range(n):
+            assert res["gt"][i].device.type == "cuda" and torch.equal(res["gt"][i].cpu(), torch.full((3 + i, 4), float(10 * k + i)))
+        assert torch.equal(res["ids"][0].cpu(), torch.full((5,), 100 * k, dtype=torch.int64))
+        assert torch.equal(res["ids"][1].cpu(), torch.full((2, 2), k, dtype=torch.int32))
+        assert torch.equal(res["nested"][0]["a"].cpu(), torch.full((2,), float(k)))
+        assert torch.equal(res["nested"][1][0].cpu(), torch.full((1,), float(-k)))
+
+    def copy(k, **kw):
+        return start_copy(batch(k, **kw), DEV, use_background_thread=background).get()
+
+    # 1. the training loop: `res = copy(...)` — the result of step k - 2 is free when step k is built
+    ids, res = [], None
+    for k in range(6):
+        res = copy(k)
+        check(res, k)
+        ids.append(id(res))
+    assert twin or (ids[4] == ids[2] and ids[5] == ids[3] and ids[4] != ids[5]), ids
+    assert twin or kept_trees() == 2
+    del res
+    # 2. results that are kept are never handed out again and keep their values
+    kept = [copy(k) for k in range(10, 14)]
+    assert len({id(r) for r in kept}) == 4
+    for r, k in zip(kept, range(10, 14)):
+        check(r, k)
+    # 3. ... nor is a tree of which only a container or a leaf is still held
+    r = copy(20)
+    inner, leaf = r["nested"], r["gt"][3]
+    del r
+    more = [copy(k) for k in range(21, 25)]
+    assert torch.equal(inner[0]["a"].cpu(), torch.full((2,), 20.0)) and torch.equal(leaf.cpu(), torch.full((6, 4), 203.0))
+    for m, k in zip(more, range(21, 25)):
+        check(m, k)
+        assert m["nested"] is not inner and all(t is not leaf for t in m["gt"])
+    del more, inner, leaf
+    # 4. a tree the caller changed (element replaced / appended, attribute on a tensor, requires_grad_) is not handed out again
+    for change in ("replace", "append", "attribute", "requires_grad"):
+        release_cached_outputs()
+        a = copy(30)
+        if change == "replace":
+            a["gt"][0] = torch.zeros(1, device=DEV)
+        elif change == "append":
+            a["gt"].append(None)
+        elif change == "attribute":
+            a["gt"][1].note = "mine"
+        else:
+            a["gt"][2].requires_grad_()
+        del a
+        b = copy(31)
+        c = copy(32)        # (a's generation is the older one now)
+        check(b, 31)
+        check(c, 32)
+        assert len(c["gt"]) == 6 and not hasattr(c["gt"][1], "note") and not c["gt"][2].requires_grad
+        del b, c
+    # 5. another pass-through object or another structure: fresh trees, right values; back to the first structure: still right
+    release_cached_outputs()
+    x = copy(40); del x
+    y = copy(41); del y
+    other = batch(42)
+    other["tag"] = object()
+    z = start_copy(other, DEV, use_background_thread=background).get()
+    assert z["tag"] is other["tag"] and z["tag"] is not tag
+    del z
+    w = copy(43, n=4)
+    check(w, 43, n=4)
+    del w
+    v = copy(44)
+    check(v, 44)
+    del v
+    # 6. outstanding handles: each result is its own
+    h1 = start_copy(batch(50), DEV, use_background_thread=background)
+    h2 = start_copy(batch(51), DEV, use_background_thread=background)
+    h3 = start_copy(batch(52), DEV, use_background_thread=background)
+    r1, r3, r2 = h1.get(), h3.get(), h2.get()
+    check(r1, 50); check(r2, 51); check(r3, 52)
+    assert len({id(r1), id(r2), id(r3)}) == 3
+    del h1, h2, h3, r1, r2, r3
+    # 7. switched off / released: nothing is kept
+    set_output_recycling(False)
+    try:
+        assert kept_trees() == 0 and (twin or copier._host.recycled_output_count() == 0)
+        p, q = copy(60), copy(61)
+        check(p, 60); check(q, 61)
+        del p, q
+        assert kept_trees() == 0
+    finally:
+        set_output_recycling(True)
+    r = copy(70); del r
+    assert twin or kept_trees() == 1
+    release_cached_outputs()
+    assert kept_trees() == 0 and (twin or copier._host.recycled_output_count() == 0)
