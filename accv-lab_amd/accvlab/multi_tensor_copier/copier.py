@@ -211,10 +211,27 @@ def nbytes_all(job: _Job) -> np.ndarray:
     return job.meta[1]
 
 
+# the plan of the last call: a training loop copies the same sizes every step, and the plan (offsets, chunk of every leaf,
+# chunk sizes, staging order) is a function of the sizes alone — 0.2 of 1.1 ms for 10 000 leaves.  The arrays are never
+# written after they were made, so handing the same ones to several jobs is safe.
+_last_plan = None
+
+
 def _plan(lib, job: _Job, nbytes: np.ndarray, esize: np.ndarray):
+    global _last_plan
     m = len(nbytes)
     nbytes = np.ascontiguousarray(nbytes, dtype=np.int64)
     esize = np.ascontiguousarray(esize, dtype=np.int32)
+    last = _last_plan
+    if last is not None and last[0] == (m, job.min_align, job.max_chunk) and np.array_equal(last[1], nbytes) and \
+            np.array_equal(last[2], esize):
+        return last[3]
+    out = _plan_uncached(lib, job, nbytes, esize, m)
+    _last_plan = ((m, job.min_align, job.max_chunk), nbytes, esize, out)
+    return out
+
+
+def _plan_uncached(lib, job: _Job, nbytes: np.ndarray, esize: np.ndarray, m: int):
     cand = np.ones(m, dtype=np.uint8)
     off = np.empty(m, dtype=np.int64)
     chk = np.empty(m, dtype=np.int64)
@@ -222,7 +239,11 @@ def _plan(lib, job: _Job, nbytes: np.ndarray, esize: np.ndarray):
     nck = ctypes.c_longlong(0)
     _nat.check(lib.accv_mtc_plan(m, nbytes.ctypes.data, esize.ctypes.data, cand.ctypes.data, job.min_align, job.max_chunk,
                                  off.ctypes.data, chk.ctypes.data, csz.ctypes.data, ctypes.addressof(nck)), "mtc_plan")
-    return off, chk, csz, int(nck.value), nbytes
+    n_chunks = int(nck.value)
+    # staging order: the leaves of a chunk one after the other (also a function of the plan alone)
+    order = np.argsort(chk, kind="stable").astype(np.int64)
+    begin = np.searchsorted(chk[order], np.arange(max(n_chunks, 0) + 1)).astype(np.int64)
+    return off, chk, csz, n_chunks, nbytes, order, begin
 
 
 def _prepare_packed_h2d(job: _Job, lib, packable: np.ndarray, side):
@@ -231,15 +252,13 @@ def _prepare_packed_h2d(job: _Job, lib, packable: np.ndarray, side):
     plan packs nothing (fewer than two candidates)."""
     dev = job.device
     route, nbytes, esize, ptr, didx = job.meta
-    off, chk, csz, n_chunks, pbytes = _plan(lib, job, nbytes[packable], esize[packable])
+    off, chk, csz, n_chunks, pbytes, order, begin = _plan(lib, job, nbytes[packable], esize[packable])
     if n_chunks <= 0:
         return None
     m = len(packable)
     align = 16
     while align < job.min_align:
         align <<= 1                    # packed_buffer_alignment_bytes, multi_tensor_copier.cpp:399-404
-    order = np.argsort(chk, kind="stable").astype(np.int64)
-    begin = np.searchsorted(chk[order], np.arange(n_chunks + 1)).astype(np.int64)
     src = np.ascontiguousarray(ptr[packable], dtype=np.uint64)
     stage_ptrs = np.empty(n_chunks, dtype=np.uint64)
     dev_ptrs = np.empty(n_chunks, dtype=np.uint64)
@@ -477,7 +496,7 @@ def _coalesced_d2d(job: _Job, lib, group: np.ndarray, src_index: int, side_dst) 
     -> typed views of one storage on the target GPU (the reference copies every tensor on its own,
     multi_tensor_copier.cpp:775-820)."""
     route, nbytes, esize, ptr, _ = job.meta
-    off, chk, csz, n_chunks, gbytes = _plan(lib, job, nbytes[group], esize[group])
+    off, chk, csz, n_chunks, gbytes = _plan(lib, job, nbytes[group], esize[group])[:5]
     if n_chunks == 0:
         return False
     sdev, ddev = torch.device("cuda", src_index), job.device
@@ -522,7 +541,7 @@ def _coalesced_d2h(job: _Job, lib, small: np.ndarray, sdev: torch.device, side) 
     """Many small device tensors -> ONE device gather kernel (accv_mtc_coalesce) -> ONE D2H transfer per chunk -> host
     views (the reference copies each tensor separately, multi_tensor_copier.cpp:790-800)."""
     route, nbytes, esize, ptr, _ = job.meta
-    off, chk, csz, n_chunks, sbytes = _plan(lib, job, nbytes[small], esize[small])
+    off, chk, csz, n_chunks, sbytes = _plan(lib, job, nbytes[small], esize[small])[:5]
     if n_chunks == 0:
         return False
     ptrs = np.ascontiguousarray(ptr[small], dtype=np.uint64)
