@@ -149,11 +149,15 @@ py::object mask_to_indices(const at::Tensor& mask, const c10::optional<at::Tenso
     return py::make_tuple(idx, sizes);
 }
 
-// depth-first flatten of nested list/tuple structures into tensor leaves; false = something else was found
-bool flatten(PyObject* obj, std::vector<at::Tensor>& out)
+// depth-first flatten of nested list/tuple structures into tensor leaves; false = something else was found.
+// The leaves are POINTERS to the tensors inside their python objects (alive for the duration of the call: the caller's
+// structure holds them): a C++ copy of a tensor handle moves the TensorImpl's reference count between 1 and 2, and each such
+// transition calls into the interpreter to pin / unpin the python object (c10/util/intrusive_ptr.h, "PyObject preservation") —
+// ~150 ns per leaf for a copy that nothing needs (csrc_host/mtc_host.cpp, LeafRef: the same finding at 10 000 leaves).
+bool flatten(PyObject* obj, std::vector<const at::Tensor*>& out)
 {
     if (THPVariable_Check(obj)) {
-        out.push_back(THPVariable_Unpack(obj));
+        out.push_back(&THPVariable_Unpack(obj));
         return true;
     }
     if (PyList_CheckExact(obj)) {
@@ -174,19 +178,21 @@ bool flatten(PyObject* obj, std::vector<at::Tensor>& out)
 // combine_data, flatten mode, CPU target: (padded [B, width, *inner], sizes int64 [B]) or None
 py::object pack_cpu(const py::object& data, bool pin, int64_t max_bytes)
 {
-    std::vector<at::Tensor> leaves;
+    std::vector<const at::Tensor*> leaves;
     if (!flatten(data.ptr(), leaves) || leaves.empty()) return py::none();
     const at::Tensor* proto = nullptr;
     int64_t width = 0;
-    for (const auto& t : leaves) {
+    for (const at::Tensor* tp : leaves) {
+        const at::Tensor& t = *tp;
         if (!t.defined() || !t.device().is_cpu() || t.requires_grad() || t.dim() < 1 || t.is_sparse() || t.is_quantized())
             return py::none();
         width = std::max<int64_t>(width, t.size(0));
-        if (!proto && t.numel() > 0) proto = &t;
+        if (!proto && t.numel() > 0) proto = tp;
     }
     if (!proto) return py::none();  // nothing but empty samples: rare, python handles it
     const auto inner = proto->sizes().slice(1);
-    for (const auto& t : leaves) {
+    for (const at::Tensor* tp : leaves) {
+        const at::Tensor& t = *tp;
         if (t.numel() == 0) continue;
         if (t.scalar_type() != proto->scalar_type() || t.sizes().slice(1) != inner) return py::none();
     }
@@ -207,7 +213,7 @@ py::object pack_cpu(const py::object& data, bool pin, int64_t max_bytes)
     const size_t row_bytes = (size_t)row_elems * proto->element_size();
     char* base = static_cast<char*>(padded.data_ptr());
     for (int64_t i = 0; i < b; ++i) {
-        const at::Tensor& t = leaves[(size_t)i];
+        const at::Tensor& t = *leaves[(size_t)i];
         const int64_t n = t.numel() == 0 ? 0 : t.size(0);
         sz[i] = n;
         if (n == 0) continue;
@@ -226,14 +232,15 @@ py::object pack_cpu(const py::object& data, bool pin, int64_t max_bytes)
 // meta int64 [2, B] = (row offsets, sizes) on the CPU — pinned if `pin` —, width) or None.
 py::object cat_leaves(const py::object& data, bool pin)
 {
-    std::vector<at::Tensor> leaves;
+    std::vector<const at::Tensor*> leaves;
     if (!flatten(data.ptr(), leaves) || leaves.empty()) return py::none();
     const at::Tensor* proto = nullptr;
     int64_t width = 0;
-    for (const auto& t : leaves) {
+    for (const at::Tensor* tp : leaves) {
+        const at::Tensor& t = *tp;
         if (!t.defined() || t.requires_grad() || t.dim() < 1 || t.is_sparse() || t.is_quantized()) return py::none();
         width = std::max<int64_t>(width, t.size(0));
-        if (!proto && t.numel() > 0) proto = &t;
+        if (!proto && t.numel() > 0) proto = tp;
     }
     if (!proto) return py::none();
     const auto inner = proto->sizes().slice(1);
@@ -245,7 +252,7 @@ py::object cat_leaves(const py::object& data, bool pin)
     parts.reserve(leaves.size());
     int64_t total = 0;
     for (int64_t i = 0; i < b; ++i) {
-        const at::Tensor& t = leaves[(size_t)i];
+        const at::Tensor& t = *leaves[(size_t)i];
         const int64_t n = t.numel() == 0 ? 0 : t.size(0);
         off[i] = total;
         sz[i] = n;
