@@ -250,7 +250,7 @@ public:
     // A generation = the packed views of one call and, when that call's result consisted of nothing else, the result TREE itself
     // (containers included) with the structure it was built from.  Round 3, second step: the other half of a many-leaf copy is
     // the life cycle of its CONTAINERS — building 12 k lists / dicts and freeing those of the previous result (1.3 of 2.4 ms for
-    // 10 000 leaves).  When the next call has the same structure (same op list, the very same key / pass-through objects) and
+    // 10 000 leaves).  When the next call has the same structure (same op list, equal keys; pass-through leaves may differ) and
     // the kept tree is held by nobody but this pool (every container referenced once — by its parent, the root by the pool —
     // and every leaf by its container slot and the pool only), the tree is handed out AGAIN: its tensors are re-pointed in
     // place, no container is built or freed.  Anything else — the caller still holds the tree or a part of it, replaced an
@@ -261,12 +261,10 @@ public:
         std::vector<at::Tensor> views;
         py::object root;                    // empty: no kept tree
         std::vector<Op> ops;
-        std::vector<py::object> objects;
         void drop_root()
         {
             root = py::object();
             ops.clear();
-            objects.clear();
         }
         void clear()
         {
@@ -362,46 +360,83 @@ public:
         PyObject** dict = _PyObject_GetDictPtr(obj);
         return dict == nullptr || *dict == nullptr || PyDict_Size(*dict) == 0;
     }
-    static bool tree_is_free(PyObject* obj, const Generation& g, size_t& cursor, size_t& obj_cursor)
+    // a pass-through slot of the kept tree whose object differs from this call's (an id, a file name, a time stamp: metadata
+    // changes every step): the slot is given the new object once the whole tree has been found free — possible in a list or a
+    // dict, not in a tuple
+    struct Patch {
+        PyObject* parent;   // list or dict (borrowed: alive with the kept tree)
+        Py_ssize_t index;   // list position, or -1 for a dict
+        PyObject* key;      // dict key (borrowed)
+        PyObject* value;    // this call's object (borrowed from objects_)
+    };
+    // keys / pass-through leaves "are the same" when they are the same object, or equal strings / integers (a dict built anew
+    // every step has equal keys that need not be the same objects)
+    static bool same_key(PyObject* kept, PyObject* now)
+    {
+        if (kept == now) return true;
+        if (PyUnicode_CheckExact(kept) && PyUnicode_CheckExact(now)) return PyUnicode_Compare(kept, now) == 0 && !PyErr_Occurred();
+        if (PyLong_CheckExact(kept) && PyLong_CheckExact(now)) return PyObject_RichCompareBool(kept, now, Py_EQ) == 1;
+        return false;
+    }
+    // Is the kept tree (structure g.ops, already known to equal this call's ops_) held by nobody but the pool, and can it carry
+    // this call's keys and pass-through objects (objects_, in traversal order)?
+    bool tree_is_free(PyObject* obj, const Generation& g, size_t& cursor, size_t& obj_cursor, std::vector<Patch>& patches,
+                      PyObject* parent, Py_ssize_t index, PyObject* key) const
     {
         if (cursor >= g.ops.size()) return false;
         const Op op = g.ops[cursor++];
         switch (op.kind) {
             case kLeaf:
                 return (size_t)op.arg < g.views.size() && leaf_is_free(obj, g.views[(size_t)op.arg]);
-            case kPass:
-                return obj_cursor < g.objects.size() && obj == g.objects[obj_cursor++].ptr();
+            case kPass: {
+                if (obj_cursor >= objects_.size()) return false;
+                PyObject* now = objects_[obj_cursor++].ptr();
+                if (obj == now) return true;
+                if (parent == nullptr || PyTuple_CheckExact(parent)) return false;   // (a tuple cannot be given another element)
+                patches.push_back({parent, index, key, now});
+                return true;
+            }
             case kList: {
                 if (!(PyList_CheckExact(obj) && Py_REFCNT(obj) == 1 && PyList_GET_SIZE(obj) == (Py_ssize_t)op.arg)) return false;
                 for (Py_ssize_t i = 0; i < (Py_ssize_t)op.arg; ++i)
-                    if (!tree_is_free(PyList_GET_ITEM(obj, i), g, cursor, obj_cursor)) return false;
+                    if (!tree_is_free(PyList_GET_ITEM(obj, i), g, cursor, obj_cursor, patches, obj, i, nullptr)) return false;
                 return true;
             }
             case kTuple: {
                 if (!(PyTuple_CheckExact(obj) && Py_REFCNT(obj) == 1 && PyTuple_GET_SIZE(obj) == (Py_ssize_t)op.arg)) return false;
                 for (Py_ssize_t i = 0; i < (Py_ssize_t)op.arg; ++i)
-                    if (!tree_is_free(PyTuple_GET_ITEM(obj, i), g, cursor, obj_cursor)) return false;
+                    if (!tree_is_free(PyTuple_GET_ITEM(obj, i), g, cursor, obj_cursor, patches, obj, i, nullptr)) return false;
                 return true;
             }
             default: {
                 if (!(PyDict_CheckExact(obj) && Py_REFCNT(obj) == 1 && PyDict_Size(obj) == (Py_ssize_t)op.arg)) return false;
-                PyObject *key, *value;
+                PyObject *k, *value;
                 Py_ssize_t pos = 0;
-                while (PyDict_Next(obj, &pos, &key, &value)) {
-                    if (!(obj_cursor < g.objects.size() && key == g.objects[obj_cursor++].ptr())) return false;
-                    if (!tree_is_free(value, g, cursor, obj_cursor)) return false;
+                while (PyDict_Next(obj, &pos, &k, &value)) {
+                    if (!(obj_cursor < objects_.size() && same_key(k, objects_[obj_cursor++].ptr()))) return false;
+                    if (!tree_is_free(value, g, cursor, obj_cursor, patches, obj, -1, k)) return false;
                 }
                 return true;
             }
         }
     }
-    bool same_structure(const Generation& g) const
+    static void apply(const std::vector<Patch>& patches)
     {
-        if (g.ops.size() != ops_.size() || g.objects.size() != objects_.size()) return false;
+        for (const Patch& p : patches) {
+            Py_INCREF(p.value);
+            if (p.index >= 0) {
+                PyList_SetItem(p.parent, p.index, p.value);        // (steals the reference, releases the old element)
+            } else {
+                PyDict_SetItem(p.parent, p.key, p.value);          // (an existing key: the dict keeps its order and size)
+                Py_DECREF(p.value);
+            }
+        }
+    }
+    bool same_structure(const Generation& g) const   // (keys and pass-through objects are compared against the kept tree itself)
+    {
+        if (g.ops.size() != ops_.size()) return false;
         for (size_t i = 0; i < ops_.size(); ++i)
-            if (g.ops[i].kind != ops_[i].kind || g.ops[i].arg != ops_[i].arg) return false;
-        for (size_t i = 0; i < objects_.size(); ++i)
-            if (g.objects[i].ptr() != objects_[i].ptr()) return false;
+            if (g.ops[i].kind != ops_[i].kind || (ops_[i].kind != kPass && g.ops[i].arg != ops_[i].arg)) return false;
         return true;
     }
 
@@ -440,7 +475,12 @@ public:
                 // the same structure, but somebody still holds (part of) the tree — normally the caller's variable of the
                 // previous step: left alone, it is free one call later
                 size_t cursor = 0, obj_cursor = 0;
-                if (tree_is_free(gen.root.ptr(), gen, cursor, obj_cursor) && cursor == gen.ops.size()) take = g;
+                std::vector<Patch> patches;
+                if (tree_is_free(gen.root.ptr(), gen, cursor, obj_cursor, patches, nullptr, -1, nullptr) && cursor == gen.ops.size() &&
+                    obj_cursor == objects_.size()) {
+                    apply(patches);   // this call's pass-through objects where they differ from the kept ones
+                    take = g;
+                }
             }
         }
         Generation taken;
@@ -497,7 +537,6 @@ public:
                 if (g.id == generation_ && g.id != 0 && g.views.size() == leaves_.size()) {
                     g.root = out;
                     g.ops = ops_;
-                    g.objects = objects_;
                 }
         }
         return out;

@@ -160,3 +160,38 @@ def test_switches():
     assert host.recycled_tree_count() == 1
     host.release_recycled_outputs()
     assert host.recycled_tree_count() == 0 and host.recycled_output_count() == 0
+
+
+def test_metadata_that_changes_every_step_rides_in_the_reused_tree():
+    """ids, names, time stamps: pass-through leaves differ every step and dict keys built per step are equal, not identical — the
+    kept tree is still handed out again, with this step's objects in its pass-through slots; a pass-through element of a TUPLE
+    cannot be replaced, so such a tree is rebuilt"""
+    def batch(k, in_tuple=False):
+        meta = {"frame " + str(1): 1000 + k, "name": f"sample_{k}", "stamp": 0.5 * k, "flags": [k, None, ("x",)]}
+        aux = (torch.full((3,), float(k)), 1000 + k) if in_tuple else [torch.full((3,), float(k)), 1000 + k]
+        return {"gt": [torch.full((2, 2), float(k)), torch.full((1,), float(-k))], "meta": meta, "aux": aux}
+
+    def check(res, k, src):
+        assert torch.equal(res["gt"][0], torch.full((2, 2), float(k))) and torch.equal(res["gt"][1], torch.full((1,), float(-k)))
+        assert torch.equal(res["aux"][0], torch.full((3,), float(k))) and res["aux"][1] == 1000 + k
+        assert res["meta"]["frame 1"] == 1000 + k and res["meta"]["name"] is src["meta"]["name"] and res["meta"]["stamp"] == 0.5 * k
+        assert res["meta"]["flags"][0] == k and res["meta"]["flags"][1] is None and res["meta"]["flags"][2] == ("x",)
+        assert list(res["meta"]) == ["frame 1", "name", "stamp", "flags"]
+
+    ids, res = [], None
+    for k in range(300, 307):          # (integers above 256 and fresh strings: new objects every step)
+        src = batch(k)
+        res = _copy(src)
+        check(res, k, src)
+        ids.append(id(res))
+    assert ids[4] == ids[2] == ids[6] and ids[5] == ids[3], ids
+    del res
+    ids = []
+    for k in range(400, 406):
+        src = batch(k, in_tuple=True)
+        res = _copy(src)
+        check(res, k, src)
+        assert isinstance(res["aux"], tuple)
+        ids.append(id(res))
+        del res
+    assert host.recycled_output_count() > 0
