@@ -348,8 +348,8 @@ def set_output_recycling(enabled: bool) -> None:
     of the last two calls and, when the next call has a packed leaf at the same position with the same dtype and device,
     re-points a kept tensor object at its new place in the new chunk — but ONLY a tensor that nothing refers to any more
     (no variable, container or view in python, nothing in C++).  A result whose leaves are all packed views is kept with its
-    containers as well and the very same tree is returned again by a later copy of the same structure (same key and
-    pass-through objects), again only when nothing refers to the tree or any part of it.  Visible effects: such an object may come back with a
+    containers as well and the very same tree is returned again by a later copy of the same structure (equal keys; non-tensor
+    leaves are replaced by the new call's), again only when nothing refers to the tree or any part of it.  Visible effects: such an object may come back with a
     new content under the same ``id()`` (a ``weakref`` to an old output is not a reference), and the chunk storage of
     up to two earlier results stays allocated (≤ 256 MB each) until the next call or :func:`release_cached_outputs`.
     """

@@ -1,5 +1,18 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p gpurun_out/r03
-timeout -k 10 600 python -m pytest tests/test_copier_gpu.py tests/test_copier_cpu.py tests/test_mtc_host_recycling_cpu.py tests/test_pipeline_gpu.py tests/test_fuzz_gpu.py -x -q -k "copier or h3 or pipeline or packed or combine or recycling" 2>&1 | tail -4 | cut -c1-300
-timeout -k 10 300 python scripts/bench_configs.py 2 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C2', d['value'], d['ms_per_step'], json.dumps(d.get('secondary'))[:600])"
+set -uo pipefail
+ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
+OUT="$ROOT/gpurun_out/r03"
+mkdir -p "$OUT"
+cd "$ROOT"
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/gpu_tests_full.log" 2>&1; rc=$?; tail -3 "$OUT/gpu_tests_full.log" | cut -c1-300; [ $rc -eq 0 ] || exit 1
+ACCV_NO_HOST_FASTPATH=1 timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/gpu_tests_python_formulations.log" 2>&1; echo "[r03] python formulations rc=$?"; tail -2 "$OUT/gpu_tests_python_formulations.log" | cut -c1-200
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "[r03] smoke rc=$?"; tail -1 "$OUT/smoke.log"
+timeout -k 10 300 python bench.py > "$OUT/bench_final.json" 2> "$OUT/bench_final.err"; echo "[r03] bench rc=$?"
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > "$OUT/bench_final_k20.json" 2> "$OUT/bench_final_k20.err"; echo "[r03] bench k20 rc=$?"
+python - <<'PY'
+import json
+for f in ("bench_final","bench_final_k20"):
+    d=json.loads(open(f"gpurun_out/r03/{f}.json").read().strip().splitlines()[-1])
+    c=d["secondary"]["configs"]
+    print(f, round(d["value"]), round(d["roofline"]["frac"],3), round(d["roofline"].get("frac_wall"),3), {k:round(v.get("value"),1) for k,v in c.items()}, "c2 ms", round(c["configs[2]"]["ms_per_step"],3), "c3 us", round(c["configs[3]"]["ms_per_step"]*1e3,2))
+PY
