@@ -8,6 +8,8 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
+#include <functional>
+
 #include <cstring>
 #include <vector>
 
@@ -248,7 +250,7 @@ py::object cat_leaves(const py::object& data, bool pin)
     at::Tensor meta = at::empty({2, b}, at::TensorOptions().dtype(at::kLong).pinned_memory(pin));
     int64_t* off = meta.data_ptr<int64_t>();
     int64_t* sz = off + b;
-    std::vector<at::Tensor> parts;
+    std::vector<std::reference_wrapper<const at::Tensor>> parts;   // (references, not handle copies: see flatten)
     parts.reserve(leaves.size());
     int64_t total = 0;
     for (int64_t i = 0; i < b; ++i) {
@@ -260,9 +262,9 @@ py::object cat_leaves(const py::object& data, bool pin)
         if (n == 0) continue;
         if (t.device() != proto->device() || t.scalar_type() != proto->scalar_type() || t.sizes().slice(1) != inner)
             return py::none();
-        parts.push_back(t);
+        parts.push_back(std::cref(t));
     }
-    at::Tensor flat = parts.size() == 1 ? parts[0].contiguous() : at::cat(parts, 0);
+    at::Tensor flat = parts.size() == 1 ? parts[0].get().contiguous() : at::cat(at::ITensorListRef(parts), 0);
     at::Tensor sizes = at::empty({b}, at::TensorOptions().dtype(at::kLong));
     std::memcpy(sizes.data_ptr<int64_t>(), sz, (size_t)b * sizeof(int64_t));
     return py::make_tuple(flat, sizes, meta, width);
