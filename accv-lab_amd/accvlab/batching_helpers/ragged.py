@@ -184,6 +184,8 @@ class RaggedBatch:
             if t.device.type == "cuda":
                 ones = torch.ones(*t.shape[:self._num_batch_dims], n, dtype=torch.bool, device=t.device)
                 self._mask = SetPaddedTo.apply(ones, self._sample_sizes, False)   # pad-fill kernel
+            elif _bh is not None and hasattr(_bh, "mask_cpu") and self._sample_sizes.device.type == "cpu":
+                self._mask = _bh.mask_cpu(self._sample_sizes, n)
             else:
                 self._mask = torch.arange(n) < self._sample_sizes.to("cpu").unsqueeze(-1)
         return self._mask

@@ -271,6 +271,26 @@ py::object cat_leaves(const py::object& data, bool pin)
 }
 
 // RaggedBatch.split for one (flattened) batch dimension: views flat[i].narrow(0, 0, sizes[i]) (+ transpose(0, back))
+// RaggedBatch.mask for host data: bool [*sizes.shape, n] with row i = (arange(n) < sizes[i]) — the four torch calls of the python
+// formulation cost 12 us for 64 samples, a quarter of configs[0]'s pack + mask + split
+at::Tensor mask_cpu(const at::Tensor& sizes, int64_t n)
+{
+    TORCH_CHECK(sizes.device().is_cpu() && n >= 0, "mask_cpu: host sizes and a non-negative width expected");
+    const at::Tensor s = sizes.scalar_type() == at::kLong ? sizes.contiguous() : sizes.to(at::kLong).contiguous();
+    std::vector<int64_t> shape(s.sizes().begin(), s.sizes().end());
+    shape.push_back(n);
+    at::Tensor out = at::empty(shape, at::TensorOptions().dtype(at::kBool));
+    const int64_t* sz = s.data_ptr<int64_t>();
+    bool* dst = out.data_ptr<bool>();
+    const int64_t rows = s.numel();
+    for (int64_t i = 0; i < rows; ++i) {
+        const int64_t k = std::min<int64_t>(std::max<int64_t>(sz[i], 0), n);
+        std::memset(dst + i * n, 1, (size_t)k);
+        std::memset(dst + i * n + k, 0, (size_t)(n - k));
+    }
+    return out;
+}
+
 std::vector<at::Tensor> split_views(const at::Tensor& flat, const std::vector<int64_t>& sizes, int64_t back)
 {
     TORCH_CHECK(flat.dim() >= 2, "split_views needs [batch, width, ...]");
@@ -318,6 +338,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("pack_cpu", &pack_cpu, py::arg("data"), py::arg("pin") = false, py::arg("max_bytes") = 0);
     m.def("cat_leaves", &cat_leaves, py::arg("data"), py::arg("pin") = false);
     m.def("split_views", &split_views);
+    m.def("mask_cpu", &mask_cpu);
     m.def("bind_native", &bind_native);
     m.def("gather_rows", &gather_rows);
     m.def("scatter_rows", &scatter_rows);

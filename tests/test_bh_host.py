@@ -252,3 +252,23 @@ def test_sizes_rewritten_behind_the_version_counter():
     ragged.forget_host_sizes(rb2.sample_sizes)
     assert [p.shape[0] for p in rb2.split()] == [1, 1, 1]
     ragged.forget_host_sizes(rb2.sample_sizes)                       # idempotent
+
+
+def test_native_cpu_mask_equals_the_python_formulation():
+    """RaggedBatch.mask for host data goes through _bh_host.mask_cpu: (arange(n) < sizes[..., None]) for any batch shape,
+    int32 / int64 sizes, zero widths and sizes outside [0, n]"""
+    from accvlab.batching_helpers import RaggedBatch, ragged
+
+    if ragged._bh is None or not hasattr(ragged._bh, "mask_cpu"):
+        pytest.skip("host extension not built")
+    g = torch.Generator().manual_seed(0)
+    for shape, n in (((7,), 5), ((2, 3), 9), ((4,), 0), ((1, 1, 2), 3)):
+        for dtype in (torch.int64, torch.int32):
+            sizes = torch.randint(-2, n + 3, shape, generator=g).to(dtype)
+            got = ragged._bh.mask_cpu(sizes, n)
+            want = torch.arange(n) < sizes.unsqueeze(-1)
+            assert got.dtype == torch.bool and got.shape == (*shape, n) and torch.equal(got, want)
+    sizes = torch.tensor([3, 0, 5])
+    rb = RaggedBatch(torch.zeros(3, 5, 2), sample_sizes=sizes)
+    assert torch.equal(rb.mask, torch.arange(5) < sizes.unsqueeze(-1))
+    assert torch.equal(ragged._bh.mask_cpu(sizes[::2], 4), torch.arange(4) < sizes[::2].unsqueeze(-1))     # non-contiguous sizes
