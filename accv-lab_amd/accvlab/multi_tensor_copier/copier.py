@@ -636,7 +636,14 @@ class AsyncCopyHandle:
                 done.record(job.side)          # every transfer of the job is on the side stream by now
                 job.events.append(done)
             if self._future is not None:
-                self._future.result()
+                future, self._future = self._future, None
+                if future.cancel():
+                    # the worker has not picked the job up yet (`start_copy(...).get()` right away): run it here instead of
+                    # waiting for a thread hand-off and the interpreter-lock ping-pong that follows it (10 000 GPU->host
+                    # leaves: 1.9 -> 1.0 ms); a job that is already running is waited for as before
+                    _run(job)
+                else:
+                    future.result()
         except BaseException as e:
             self._error = e
             _abandon(job)
