@@ -1,4 +1,4 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p gpurun_out/r03
-timeout -k 10 600 python -m pytest tests/test_copier_gpu.py tests/test_copier_cpu.py tests/test_pipeline_gpu.py tests/test_fuzz_gpu.py -x -q -k "copier or h3 or pipeline or packed or combine or recycling" 2>&1 | tail -3 | cut -c1-300
-timeout -k 10 500 python scripts/bench_secondary.py --configs C2 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03/secondary_c2_final.log | cut -c1-400
+ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"; OUT="$ROOT/gpurun_out/r03"; mkdir -p "$OUT"; cd "$ROOT"
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/gpu_tests_full.log" 2>&1; echo "rc=$?"; tail -2 "$OUT/gpu_tests_full.log" | cut -c1-200
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
