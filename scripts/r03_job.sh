@@ -1,4 +1,3 @@
 #!/bin/bash
-ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"; OUT="$ROOT/gpurun_out/r03"; mkdir -p "$OUT"; cd "$ROOT"
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/gpu_tests_full.log" 2>&1; echo "rc=$?"; tail -2 "$OUT/gpu_tests_full.log" | cut -c1-200
-timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+cd "${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p gpurun_out/r03
+timeout -k 10 600 python scripts/bench_secondary.py --configs F4 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03/secondary_f4_final.log | cut -c1-500
