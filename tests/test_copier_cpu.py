@@ -269,3 +269,45 @@ def test_output_tensor_objects_are_recycled_only_when_nothing_refers_to_them():
     b = result(21)
     assert host.recycled_output_count() == 0 and b["a"].tolist() == [21.0] * 4
     copier.set_output_recycling(True)
+
+
+def test_background_job_runs_exactly_once_whether_get_comes_early_or_late(monkeypatch):
+    """get() on a job the worker pool has not started yet takes it over and runs it on the caller's thread; a job that is
+    running or done is waited for — either way the orchestration runs once and the result is right"""
+    import threading
+    import time
+
+    from accvlab.multi_tensor_copier import copier, start_copy
+
+    calls, threads = [], []
+    real_run = copier._run
+
+    def counting_run(job):
+        calls.append(1)
+        threads.append(threading.current_thread().name)
+        return real_run(job)
+
+    monkeypatch.setattr(copier, "_run", counting_run)
+    data = {"a": [torch.arange(5), torch.ones(2, 3)], "b": (np.arange(4, dtype=np.float32), "tag")}
+
+    def check(res):
+        assert torch.equal(res["a"][0], torch.arange(5)) and torch.equal(res["a"][1], torch.ones(2, 3))
+        assert torch.equal(res["b"][0], torch.arange(4, dtype=torch.float32)) and res["b"][1] == "tag"
+
+    for wait in (0.0, 0.2):
+        calls.clear()
+        h = start_copy(data, "cpu", use_background_thread=True)
+        if wait:
+            time.sleep(wait)            # the worker has long finished
+        check(h.get())
+        check(h.get())                  # a second get() returns the same result without running anything
+        assert len(calls) == 1, (wait, calls, threads)
+    # ready() polling until done, then get(): still once
+    calls.clear()
+    h = start_copy(data, "cpu", use_background_thread=True)
+    t0 = time.time()
+    while not h.ready():
+        assert time.time() - t0 < 10
+        time.sleep(0.001)
+    check(h.get())
+    assert len(calls) == 1
