@@ -230,6 +230,15 @@ __device__ __forceinline__ Cand cull_load(const TileCtx& t, int base, int lane)
         const float2 c = t.centers_f[cc];
         const float4 b = t.boxes_f[cc];
         const float m = fminf(fminf(c.x - b.x, c.y - b.y), fminf(b.z - c.x, b.w - c.y));
+        // (a stride that is a power of two: the product with its reciprocal is the same correctly rounded value as the IEEE
+        // division — both round x * 2^-k once — for a third of the instructions of this cull)
+        const bool pow2 = (__float_as_uint(t.stride) & 0x007fffffu) == 0u && t.stride > 1.0e-30f && t.stride < 1.0e30f;   // uniform
+        if (pow2) {
+            const float inv = 1.0f / t.stride;
+            int r = (int)ceilf(m * inv);
+            if (r < 1) r = 1;
+            return Cand{(int)(c.x * inv), (int)(c.y * inv), r, 0};
+        }
         int r = (int)ceilf(__fdiv_rn(m, t.stride));
         if (r < 1) r = 1;
         return Cand{(int)__fdiv_rn(c.x, t.stride), (int)__fdiv_rn(c.y, t.stride), r, 0};
