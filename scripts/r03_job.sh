@@ -1,6 +1,17 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-$(pwd)}"; mkdir -p gpurun_out/r03
-timeout -k 10 600 python -m pytest tests/test_multiscale_gpu.py tests/test_targets_multiscale_gpu.py tests/test_fuzz_gpu.py tests/test_config_sizes_gpu.py -m gpu -x -q 2>&1 | tail -2
-for i in 1 2; do timeout -k 10 300 python scripts/box_maps_floor_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-400; done
-timeout -k 10 200 python scripts/bench_configs.py 3 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['secondary']; print('step', round(d['ms_per_step']*1e3,2), d['value'], 'box', round(s['box_maps_only_ms']*1e3,2), 'lanes', round(s['lane_raster_only_ms']*1e3,2))"
+set -uo pipefail
+ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
+OUT="$ROOT/gpurun_out/r03"
+mkdir -p "$OUT"
+cd "$ROOT"
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/gpu_tests_full.log" 2>&1; rc=$?; tail -3 "$OUT/gpu_tests_full.log" | cut -c1-300; [ $rc -eq 0 ] || exit 1
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "[r03] smoke rc=$?"; tail -1 "$OUT/smoke.log"
+timeout -k 10 300 python bench.py > "$OUT/bench_final.json" 2> "$OUT/bench_final.err"; echo "[r03] bench rc=$?"
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > "$OUT/bench_final_k20.json" 2> "$OUT/bench_final_k20.err"; echo "[r03] bench k20 rc=$?"
+python - <<'PY'
+import json
+for f in ("bench_final","bench_final_k20"):
+    d=json.loads(open(f"gpurun_out/r03/{f}.json").read().strip().splitlines()[-1])
+    c=d["secondary"]["configs"]
+    print(f, round(d["value"]), round(d["roofline"]["frac"],3), round(d["roofline"].get("frac_wall"),3), {k:round(v.get("value"),1) for k,v in c.items()})
+PY
